@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the retrieval scoring path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric "queries/sec @ top-10, 10M x 768 bf16 corpus, 1-8 GPUs"):
+every GPU holds a 10M x 768 bf16 shard of unit-normalised synthetic rows (weak scaling: N GPUs
+= N x 10M rows; --rows-per-gpu 12500000 gives configs[3]'s 100M rows at N=8), the query batch is
+256 (configs[3]) at top-10.  One step = one batch through the whole hot path: sample scan, tau
+select, filtered scan with the fused top-k filter, exact re-score + certificate, RCCL
+all-gather of the per-shard candidates (N > 1), merge + symbol/path rerank.  Inputs (corpus,
+queries, metadata columns, symbol hashes) are resident in HBM before the timed region.
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel (the filter-pass scan), timed
+with HIP events on its own stream inside the library (crag_set_profiling).  `cpu_baseline` is
+the oracle's C port timed on the host cores on a bounded sample (rank 0, N=1 only).
+`regimes` adds the two other regimes north_star names (batch-1 GEMV, batch-1024 top-100 MFMA),
+measured on the same corpus after the timed region; they are not part of `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "code-rag_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the extra regimes")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import coderag_hip as ch
+    from coderag_hip.dist import ShardedSearcher
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, d, B, top_k = args.rows_per_gpu, args.dim, args.batch, args.top_k
+
+    # ---- synthetic shard, generated on the device in chunks -----------
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    rows = torch.empty((n, d), dtype=torch.bfloat16, device=dev)
+    step_rows = 1_000_000
+    for lo in range(0, n, step_rows):
+        m = min(step_rows, n - lo)
+        x = torch.randn((m, d), generator=g, device=dev, dtype=torch.float32)
+        rows[lo:lo + m] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    del x
+    gq = torch.Generator(device=dev).manual_seed(1235)  # same queries on every rank
+    q = torch.randn((max(B, 1024), d), generator=gq, device=dev, dtype=torch.float32)
+    q = (q / q.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    # metadata columns (configs[4] mix): path class {70% neutral, 25% boosted, 5% penalised},
+    # names Zipf-drawn from a 50k-symbol dictionary; each query mentions 2 dictionary symbols
+    n_sym = 50_000
+    sym_hash, sym_len = ch.hash_names([f"sym{i}" for i in range(n_sym)])
+    sym_hash_t = torch.from_numpy(sym_hash.view(np.int64)).to(dev)
+    gz = torch.Generator(device=dev).manual_seed(99 + rank)
+    zipf = (torch.rand((n,), generator=gz, device=dev).pow(3.0) * n_sym).long().clamp_(max=n_sym - 1)
+    name_hash = sym_hash_t[zipf].contiguous()
+    u = torch.rand((n,), generator=gz, device=dev)
+    path_class = torch.where(u < 0.70, 0, torch.where(u < 0.95, 2, 1)).to(torch.uint8).contiguous()
+    del zipf, u
+    rng = np.random.default_rng(7)
+    qsyms = np.sort(sym_hash[rng.integers(0, n_sym, size=(q.shape[0], 2))], axis=1)
+    q_hashes = torch.from_numpy(qsyms.reshape(-1).view(np.int64).copy()).to(dev)
+    q_hash_off = torch.arange(0, 2 * q.shape[0] + 1, 2, dtype=torch.int32, device=dev)
+
+    col = ch.GpuCollection(d, "bf16", "l2", device=local_rank)
+    col.attach_device(rows, name_hash, path_class)
+    col.set_symbols(sym_hash, sym_len)
+    col.set_id_base(rank * n)
+    col.finalize()
+    sharded = ShardedSearcher(col, rank, world) if world > 1 else None
+    qb = q[:B].contiguous()
+
+    def step():
+        if sharded is not None:
+            return sharded.search_device(qb, top_k, 2.0, q_hashes, q_hash_off)
+        return col.search_device(qb, top_k, 2.0, q_hashes, q_hash_off)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    col.stats(reset=True)
+    col.profile(reset=True)
+    col.set_profiling(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    col.set_profiling(False)
+    prof = col.profile(reset=True)
+    st = col.stats(reset=True)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    qps = B * args.steps / dt
+
+    # ---- roofline of the dominant kernel (filter-pass scan) ----------------------------------
+    scan_ms = prof["filter_scan_ms"] / max(prof["searches"], 1)
+    alg_bytes = n * d * 2 + n * 4          # rows once + |x|^2 column, per launch
+    flops = 2.0 * B * n * d
+    achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
+    roofline = {
+        "kernel": "k_scan_mfma (filter pass)" if B >= 16 else "k_scan_gemv (filter pass)",
+        "bound": "hbm" if hbm_bound else "mfma",
+        "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
+        "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,
+        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": round((achieved_gbs / HBM_PEAK_GBS) if hbm_bound else (flops / (scan_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF), 4),
+        "traffic": None,
+        "kernel_ms": round(scan_ms, 4),
+        "algorithmic_bytes": alg_bytes,
+        "mfma_tflops": round(flops / (scan_ms * 1e-3) / 1e12, 2) if scan_ms > 0 else 0.0,
+        "mfma_frac": round(flops / (scan_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if scan_ms > 0 else 0.0,
+    }
+
+    line = {
+        "metric": "queries/sec @ top-10, 10M x 768 bf16 corpus",
+        "value": round(qps, 2),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"{n} x {d} bf16 unit-norm rows per GPU ({world * n} total), batch-{B} queries, "
+                               f"top-{top_k} (2*top_k={2 * top_k} candidates), squared-L2, symbolBoost=2.0 rerank, "
+                               "row-sharded with one RCCL all-gather of candidates" if world > 1 else
+                               f"{n} x {d} bf16 unit-norm rows, batch-{B} queries, top-{top_k} "
+                               f"(2*top_k={2 * top_k} candidates), squared-L2, symbolBoost=2.0 rerank, single MI355X",
+                   "rows_per_gpu": n, "dim": d, "batch": B, "top_k": top_k, "parallelism": f"rows/{world}"},
+        "roofline": roofline,
+        "exact_fallback_queries": st["fallback"],
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        line["regimes"] = extra_regimes(col, q, n, d, torch)
+        line["cpu_baseline"] = cpu_baseline(rows, q, n, d, top_k, args.cpu_sample_rows, torch, np)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extra_regimes(col, q, n, d, torch):
+    """batch-1 (HBM-bound GEMV) and batch-1024 top-100 (MFMA-bound GEMM) on the same corpus."""
+    out = []
+    for name, B, top_k, path, steps in (("batch-1 top-10 GEMV", 1, 10, "gemv", 20), ("batch-8 top-10 GEMV", 8, 10, "gemv", 10),
+                                        ("batch-1024 top-100 MFMA", 1024, 100, "mfma", 5)):
+        col.set_path(path)
+        qb = q[:B].contiguous()
+        for _ in range(2):
+            col.search_device(qb, top_k, 2.0)
+        col.profile(reset=True)
+        col.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            col.search_device(qb, top_k, 2.0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        col.set_profiling(False)
+        prof = col.profile(reset=True)
+        ms = prof["filter_scan_ms"] / max(prof["searches"], 1)
+        gbs = (n * d * 2 + n * 4) / (ms * 1e-3) / 1e9
+        tf = 2.0 * B * n * d / (ms * 1e-3) / 1e12
+        out.append({"regime": name, "queries_per_s": round(B * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 4),
+                    "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
+    col.set_path("auto")
+    return out
+
+
+def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
+    """The oracle's C port (oracle/crag_oracle.c: oracle_knn_fast_f32, OpenMP over rows) on the
+    host cores, on the first `sample_rows` rows; the scan is linear in rows, so q/s for the full
+    corpus is the sample rate times sample_rows/n (stated in `sample`)."""
+    from oracle import coracle
+    coracle.build()
+    m = min(sample_rows, n)
+    host_rows = rows[:m].view(torch.int16).cpu().numpy().view(np.uint16)
+    nq = 16
+    host_q = q[:nq].view(torch.int16).cpu().numpy().view(np.uint16)
+    coracle.knn_fast_f32(host_rows[:10000], host_q[:1], 2 * top_k)  # warm the library
+    t0 = time.perf_counter()
+    coracle.knn_fast_f32(host_rows, host_q, 2 * top_k)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    qps_sample = nq / dt
+    return {"value": round(qps_sample * m / n, 4), "unit": "queries/s", "cores": cores, "kind": "port",
+            "host_cpus_visible": os.cpu_count(),
+            "sample": f"{nq} queries x first {m} of {n} rows in {dt:.2f} s (float32 brute force + (dist,id) top-{2 * top_k}, "
+                      f"OpenMP {cores} threads); value = sample q/s x {m}/{n}"}
+
+
+if __name__ == "__main__":
+    main()

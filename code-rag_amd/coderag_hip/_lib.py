@@ -1,0 +1,89 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libcoderag_hip.so (the C ABI of include/coderag_hip.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is present, the
+product path raises.  The library is built in-tree by code-rag_amd/build.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcoderag_hip.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+METRIC_L2, METRIC_IP = 0, 1
+ENTRY_BYTES = 16
+MAX_TOP_K = 200
+
+# every symbol include/coderag_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "crag_version", "crag_last_error", "crag_device_count",
+    "crag_index_create", "crag_index_destroy", "crag_index_size", "crag_index_dim_pad",
+    "crag_index_set_id_base", "crag_index_add", "crag_index_add_device", "crag_index_attach_device",
+    "crag_index_set_symbols", "crag_index_finalize",
+    "crag_hash_name", "crag_hash_names", "crag_symbol_hashes",
+    "crag_search", "crag_search_multi", "crag_search_device",
+    "crag_search_local_device", "crag_merge_rerank_device",
+    "crag_stats", "crag_set_path", "crag_set_profiling", "crag_get_profile",
+]
+
+_lib = None
+
+
+class CragError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CragError(
+            f"{LIB_PATH} is missing: build it with `python code-rag_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    lib.crag_version.restype = i32
+    lib.crag_last_error.restype = C.c_char_p
+    lib.crag_device_count.restype = i32
+    lib.crag_index_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    lib.crag_index_destroy.argtypes = [vp]
+    lib.crag_index_size.argtypes = [vp]
+    lib.crag_index_size.restype = i64
+    lib.crag_index_dim_pad.argtypes = [vp]
+    lib.crag_index_set_id_base.argtypes = [vp, i64]
+    lib.crag_index_add.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.crag_index_add_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.crag_index_attach_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.crag_index_set_symbols.argtypes = [vp, vp, vp, i64]
+    lib.crag_index_finalize.argtypes = [vp]
+    lib.crag_hash_name.argtypes = [C.c_char_p, i64]
+    lib.crag_hash_name.restype = C.c_uint64
+    lib.crag_hash_names.argtypes = [C.c_char_p, vp, i64, vp]
+    lib.crag_hash_names.restype = None
+    lib.crag_symbol_hashes.argtypes = [vp, C.c_char_p, i64, vp, i32]
+    lib.crag_search.argtypes = [vp, vp, i32, i32, f64, C.c_char_p, vp, vp, vp, vp, vp]
+    lib.crag_search_multi.argtypes = [vp, vp, i32, i32, f64, C.c_char_p, vp, vp, vp, vp, vp]
+    lib.crag_search_device.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]
+    lib.crag_search_local_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.crag_merge_rerank_device.argtypes = [i32, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]
+    lib.crag_stats.argtypes = [vp, vp, i32]
+    lib.crag_set_path.argtypes = [vp, i32]
+    lib.crag_set_profiling.argtypes = [vp, i32]
+    lib.crag_get_profile.argtypes = [vp, vp, i32]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("crag_version", "crag_device_count"):
+            fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = load().crag_last_error().decode("utf-8", "replace")
+        raise CragError(f"{what or 'coderag_hip'} failed ({rc}): {msg}")
+    return rc

@@ -1,0 +1,107 @@
+# -*- coding: utf-8 -*-
+"""On-disk collection format: what stands where Chroma's
+`data/chroma_db` persistence stands in the reference (indexer/embed_ingest.py:77-105).
+
+    <db_path>/<collection_name>/meta.json     {"dim", "dtype", "metric", "count"}
+    <db_path>/<collection_name>/rows.npy      [count, dim] float32, or uint16 bf16 bit patterns
+    <db_path>/<collection_name>/chunks.jsonl  one {"id", "meta", "text"} per row (the chunker's
+                                              record shape, indexer/chunker.py:270-278)
+
+`ingest_chunks` is the run_ingest of embed_ingest.py:57-132 with the embeddings produced by the
+injected embed_fn; metadata is sanitised like embed_ingest.py:26-35.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Any, Callable, Dict, Iterable, List, Optional
+
+import numpy as np
+
+
+def sanitize_metadata(meta: Dict[str, Any]) -> Dict[str, Any]:
+    out = {}
+    for k, v in meta.items():
+        if v is None:
+            out[k] = ""
+        elif isinstance(v, (bool, int, float, str)):
+            out[k] = v
+        else:
+            out[k] = str(v)
+    return out
+
+
+def iter_jsonl(path: str):
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if line:
+                yield json.loads(line)
+
+
+def save_collection(db_path: str, col) -> str:
+    d = os.path.join(db_path, col.name)
+    os.makedirs(d, exist_ok=True)
+    rows = col._host_rows()
+    np.save(os.path.join(d, "rows.npy"), rows)
+    with open(os.path.join(d, "chunks.jsonl"), "w", encoding="utf-8") as f:
+        for cid, m, doc in zip(col.ids, col.metadatas, col.documents):
+            f.write(json.dumps({"id": cid, "meta": m, "text": doc}, ensure_ascii=False) + "\n")
+    with open(os.path.join(d, "meta.json"), "w") as f:
+        json.dump({"dim": col.gpu.dim, "dtype": col.gpu.dtype, "metric": col.gpu.metric, "count": col.count()}, f)
+    return d
+
+
+def load_collection(db_path: str, name: str, device: int = 0):
+    from .hybrid_search import ChunkCollection
+    d = os.path.join(db_path, name)
+    with open(os.path.join(d, "meta.json")) as f:
+        meta = json.load(f)
+    rows = np.load(os.path.join(d, "rows.npy"), allow_pickle=False)
+    col = ChunkCollection(name, meta["dim"], meta["dtype"], meta.get("metric", "l2"), device)
+    ids, metas, docs = [], [], []
+    for obj in iter_jsonl(os.path.join(d, "chunks.jsonl")):
+        ids.append(obj["id"])
+        metas.append(obj.get("meta"))
+        docs.append(obj.get("text"))
+    if len(ids) != rows.shape[0]:
+        raise ValueError("rows.npy and chunks.jsonl disagree")
+    if ids:
+        col.add(ids, rows, metas, docs)
+    col.gpu.finalize()
+    return col
+
+
+def ingest_chunks(searcher, chunks_path: str, collection: str = "code_chunks", batch_size: int = 100,
+                  fresh: bool = False, persist: bool = True) -> Dict[str, Any]:
+    """embed_ingest.py:57-132: JSONL of {id, text, meta} -> collection, batches of `batch_size`."""
+    assert os.path.exists(chunks_path), f"chunks file not found: {chunks_path}"
+    probe = np.asarray(searcher.ef(["probe"]), np.float32)
+    col = searcher.create_collection(collection, probe.shape[-1], fresh=fresh)
+    ids: List[str] = []
+    docs: List[str] = []
+    metas: List[Dict[str, Any]] = []
+    total = 0
+
+    def flush():
+        if not ids:
+            return
+        emb = np.asarray(searcher.ef(list(docs)), np.float32)
+        col.add(list(ids), emb, list(metas), list(docs))
+        ids.clear()
+        docs.clear()
+        metas.clear()
+
+    for obj in iter_jsonl(chunks_path):
+        ids.append(obj["id"])
+        docs.append(obj["text"])
+        metas.append(sanitize_metadata(obj.get("meta", {})))
+        total += 1
+        if len(ids) >= int(batch_size):
+            flush()
+    flush()
+    col.gpu.finalize()
+    if persist:
+        save_collection(searcher.db_path, col)
+    return {"chunks": chunks_path, "db": searcher.db_path, "collection": collection, "fresh": fresh,
+            "batch_size": int(batch_size), "input_count": total, "collection_count": col.count()}

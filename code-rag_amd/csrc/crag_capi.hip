@@ -1,0 +1,881 @@
+// Host side of the C ABI declared in include/coderag_hip.h (gfx950 only, no CPU fallback:
+// every search runs the HIP kernels or fails with CRAG_E_HIP).
+//
+// Pipeline of one search (replaces hybrid_search.py:60-125 of the reference):
+//   1 sample pass   dense scores of the first n_sample rows            (K1 or K2, mode 0)
+//   2 k_tau_select  per query threshold tau = M-th smallest sample score
+//   3 filter pass   full scan, fused compare-and-append of the rare s <= tau rows (mode 1)
+//   4 k_finalize    sort candidates, exact fp64 re-score of the M best, certificate, entries
+//   5 k_merge_rerank  merge shards, base score, path/symbol boost, filter, stable sort, top_k
+//   (+ exact fallback scan for queries whose certificate failed or whose buffer overflowed)
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/coderag_hip.h"
+#include "crag_common.h"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(CRAG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                        ":" + std::to_string(__LINE__) + ")");                            \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(CRAG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Workspace {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf q, desc, tau, cntst, sample, cand, entries, qhash, out, keys, misc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan timing (crag_set_profiling)
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    int ensure_events() {
+        for (auto& e : ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) return fail(CRAG_E_HIP, "hipEventCreate failed");
+        return 0;
+    }
+    int ensure_pinned(size_t bytes) {
+        if (bytes <= pinned_cap) return 0;
+        if (pinned) (void)hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_cap = 0;
+        size_t want = bytes * 2 + 4096;
+        hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(CRAG_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        pinned_cap = want;
+        return 0;
+    }
+};
+
+std::mutex g_pool_mu;
+std::vector<Workspace*> g_pool;  // free workspaces, any device
+
+Workspace* ws_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i]->device == device) {
+                Workspace* w = g_pool[i];
+                g_pool.erase(g_pool.begin() + (long)i);
+                return w;
+            }
+    }
+    Workspace* w = new Workspace();
+    w->device = device;
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
+void ws_release(Workspace* w) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(w);
+}
+struct WsGuard {
+    Workspace* w;
+    explicit WsGuard(int device) : w(ws_acquire(device)) {}
+    ~WsGuard() {
+        if (w) ws_release(w);
+    }
+};
+
+const int kChunkSizes[] = {32, 48, 64, 96, 128, 192, 256};
+
+inline uint64_t fnv1a(const unsigned char* p, int64_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h ? h : 1ull;
+}
+
+inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+}  // namespace
+
+struct crag_index {
+    int dim = 0, dim_pad = 0, dtype = 0, metric = 0, device = 0, chunks = 0;
+    size_t esz = 4;
+    int64_t n_rows = 0, cap_rows = 0;
+    int64_t id_base = 0;
+    void* rows = nullptr;
+    bool owns_rows = true, attached = false;
+    float* xnorm = nullptr;
+    float max_xnorm = 0.f;
+    bool finalized = false;
+    uint64_t* name_hash = nullptr;
+    uint8_t* path_class = nullptr;
+    bool owns_meta = true;
+    std::unordered_set<uint64_t> names;
+    std::vector<uint8_t> len_present;  // index = byte length
+    int max_name_len = 0;
+    int force_path = 0;
+    int profiling = 0;
+    std::mutex prof_mu;
+    double prof[4] = {0, 0, 0, 0};  // sample-scan ms, filter-scan ms, searches timed, unused
+    std::atomic<long long> stats[7];
+    crag_index() {
+        for (auto& s : stats) s = 0;
+    }
+};
+
+namespace {
+
+int grow(crag_index* h, int64_t need_rows, bool need_hash, bool need_class) {
+    if (h->attached) return fail(CRAG_E_STATE, "collection is attached to caller memory; cannot add rows");
+    int64_t cap = h->cap_rows;
+    bool realloc_rows = need_rows > cap;
+    if (realloc_rows) {
+        cap = std::max<int64_t>(need_rows, cap + cap / 2);
+        cap = std::max<int64_t>(cap, 1024);
+    }
+    const size_t row_bytes = (size_t)h->dim_pad * h->esz;
+    if (realloc_rows) {
+        void* nr = nullptr;
+        HIPCHK(hipMalloc(&nr, (size_t)cap * row_bytes));
+        if (h->n_rows) HIPCHK(hipMemcpy(nr, h->rows, (size_t)h->n_rows * row_bytes, hipMemcpyDeviceToDevice));
+        if (h->rows) (void)hipFree(h->rows);
+        h->rows = nr;
+    }
+    if ((need_hash || h->name_hash) && (realloc_rows || !h->name_hash)) {
+        uint64_t* nh = nullptr;
+        HIPCHK(hipMalloc((void**)&nh, (size_t)cap * 8));
+        HIPCHK(hipMemset(nh, 0, (size_t)cap * 8));
+        if (h->name_hash && h->n_rows)
+            HIPCHK(hipMemcpy(nh, h->name_hash, (size_t)h->n_rows * 8, hipMemcpyDeviceToDevice));
+        if (h->name_hash) (void)hipFree(h->name_hash);
+        h->name_hash = nh;
+    }
+    if ((need_class || h->path_class) && (realloc_rows || !h->path_class)) {
+        uint8_t* nc = nullptr;
+        HIPCHK(hipMalloc((void**)&nc, (size_t)cap));
+        HIPCHK(hipMemset(nc, 0, (size_t)cap));
+        if (h->path_class && h->n_rows) HIPCHK(hipMemcpy(nc, h->path_class, (size_t)h->n_rows, hipMemcpyDeviceToDevice));
+        if (h->path_class) (void)hipFree(h->path_class);
+        h->path_class = nc;
+    }
+    h->cap_rows = cap;
+    return 0;
+}
+
+int add_common(crag_index* h, const void* rows, int64_t n, const uint64_t* name_hash, const uint8_t* path_class,
+               hipMemcpyKind kind) {
+    if (!h || n < 0 || (n > 0 && !rows)) return fail(CRAG_E_INVALID, "crag_index_add: bad arguments");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = grow(h, h->n_rows + n, name_hash != nullptr, path_class != nullptr);
+    if (rc) return rc;
+    const size_t src_pitch = (size_t)h->dim * h->esz, dst_pitch = (size_t)h->dim_pad * h->esz;
+    char* dst = (char*)h->rows + (size_t)h->n_rows * dst_pitch;
+    if (src_pitch == dst_pitch) {
+        HIPCHK(hipMemcpy(dst, rows, (size_t)n * dst_pitch, kind));
+    } else {
+        HIPCHK(hipMemset(dst, 0, (size_t)n * dst_pitch));
+        HIPCHK(hipMemcpy2D(dst, dst_pitch, rows, src_pitch, src_pitch, (size_t)n, kind));
+    }
+    if (name_hash) HIPCHK(hipMemcpy(h->name_hash + h->n_rows, name_hash, (size_t)n * 8, kind));
+    if (path_class) HIPCHK(hipMemcpy(h->path_class + h->n_rows, path_class, (size_t)n, kind));
+    h->n_rows += n;
+    h->finalized = false;
+    return 0;
+}
+
+long long n_sample_for(long long N, int M) {
+    if (N <= 0) return 0;
+    long long t = (long long)((double)N * (double)M / 2048.0);
+    t = std::min(t, N / 16);
+    t = std::max<long long>(t, 4096);
+    t = (t + 127) / 128 * 128;
+    return std::min(t, N);
+}
+
+struct Plan {
+    int B = 0, top_k = 0, kc = 0, M = 0;
+    bool mfma = false;
+    int nq_template = 1;
+    int n_groups = 0;
+    int blocks[2] = {0, 0};
+    long long sample_stride = 0;
+};
+
+// one batch on one device: queries already on the device in index dtype, row stride dim_pad
+int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
+                   const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
+                   hipStream_t st) {
+    crag_index* h0 = hs[0];
+    Plan P;
+    P.B = B;
+    P.top_k = top_k;
+    P.kc = 2 * top_k;  // hybrid_search.py:62
+    P.M = P.kc + std::max(16, P.kc / 4);
+    if (P.M > CRAG_MAX_M) P.M = CRAG_MAX_M;
+
+    const int path = h0->force_path;
+    P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 16));
+
+    // ---- descriptors ----
+    std::vector<QueryDesc> qd((size_t)B);
+    std::vector<GroupDesc> gd;
+    for (int b = 0; b < B; ++b) {
+        crag_index* h = hs[b];
+        QueryDesc& d = qd[(size_t)b];
+        d.rows = h->rows;
+        d.xnorm = h->xnorm;
+        d.name_hash = (const unsigned long long*)h->name_hash;
+        d.path_class = h->path_class;
+        d.n_rows = h->n_rows;
+        d.n_sample = n_sample_for(h->n_rows, P.M);
+        d.id_base = h->id_base;
+        d.max_xnorm = h->max_xnorm;
+        d.pad = 0;
+        P.sample_stride = std::max<long long>(P.sample_stride, d.n_sample);
+    }
+    P.sample_stride = (P.sample_stride + 63) / 64 * 64;
+    if (!P.mfma) {
+        int b = 0;
+        int max_nq = 1;
+        while (b < B) {
+            int e = b + 1;
+            while (e < B && e - b < CRAG_MAX_GROUP_Q && hs[e] == hs[b]) ++e;
+            GroupDesc g;
+            memset(&g, 0, sizeof(g));
+            g.rows = hs[b]->rows;
+            g.xnorm = hs[b]->xnorm;
+            g.n_rows = hs[b]->n_rows;
+            g.n_sample = qd[(size_t)b].n_sample;
+            g.q_first = b;
+            g.nq = e - b;
+            max_nq = std::max(max_nq, g.nq);
+            gd.push_back(g);
+            b = e;
+        }
+        P.nq_template = max_nq <= 1 ? 1 : (max_nq <= 2 ? 2 : (max_nq <= 4 ? 4 : 8));
+        const int RT = 64 / P.nq_template;
+        const long long max_waves = 256LL * 12;
+        for (int mode = 0; mode < 2; ++mode) {
+            long long total_st = 0;
+            for (auto& g : gd) total_st += ((mode ? g.n_rows : g.n_sample) + RT - 1) / RT;
+            int blk = 0;
+            for (auto& g : gd) {
+                const long long stg = ((mode ? g.n_rows : g.n_sample) + RT - 1) / RT;
+                g.blk_first[mode] = blk;
+                if (stg == 0) {
+                    g.n_blk[mode] = 0;
+                    continue;
+                }
+                long long share = std::max<long long>(4, max_waves * stg / std::max<long long>(total_st, 1));
+                long long waves = std::min(stg, share);
+                const long long T = (stg + waves - 1) / waves;
+                waves = (stg + T - 1) / T;
+                g.n_blk[mode] = (int)((waves + 3) / 4);
+                blk += g.n_blk[mode];
+            }
+            P.blocks[mode] = blk;
+        }
+    }
+    P.n_groups = (int)gd.size();
+
+    // ---- workspace ----
+    const size_t desc_bytes = sizeof(QueryDesc) * (size_t)B + sizeof(GroupDesc) * gd.size();
+    int rc;
+    if ((rc = ws->ensure_pinned(desc_bytes))) return rc;
+    if ((rc = ws->desc.ensure(desc_bytes))) return rc;
+    if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
+    if ((rc = ws->cntst.ensure(sizeof(uint32_t) * 2 * (size_t)B))) return rc;
+    if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)P.sample_stride))) return rc;
+    if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * CRAG_CAND_CAP))) return rc;
+    memcpy(ws->pinned, qd.data(), sizeof(QueryDesc) * (size_t)B);
+    if (!gd.empty()) memcpy((char*)ws->pinned + sizeof(QueryDesc) * (size_t)B, gd.data(), sizeof(GroupDesc) * gd.size());
+    HIPCHK(hipMemcpyAsync(ws->desc.p, ws->pinned, desc_bytes, hipMemcpyHostToDevice, st));
+    const QueryDesc* qd_dev = (const QueryDesc*)ws->desc.p;
+    const GroupDesc* gd_dev = (const GroupDesc*)((char*)ws->desc.p + sizeof(QueryDesc) * (size_t)B);
+    uint32_t* cnt = (uint32_t*)ws->cntst.p;
+    uint32_t* status = cnt + B;
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)B, st));
+
+    // ---- passes ----
+    const bool prof = h0->profiling != 0;
+    if (prof && (rc = ws->ensure_events())) return rc;
+    if (P.mfma) {
+        MfmaArgs a;
+        a.rows = h0->rows;
+        a.xnorm = h0->xnorm;
+        a.n_rows = h0->n_rows;
+        a.queries = q_dev;
+        a.n_queries = B;
+        a.dim_pad = h0->dim_pad;
+        a.metric = h0->metric;
+        a.tau = (const float*)ws->tau.p;
+        a.sample = (uint32_t*)ws->sample.p;
+        a.sample_stride = P.sample_stride;
+        a.cand = (unsigned long long*)ws->cand.p;
+        a.cnt = cnt;
+        a.row_begin = 0;
+        a.row_end = qd[0].n_sample;
+        if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
+        if ((rc = crag_launch_scan_mfma(a, 0, st))) return fail(CRAG_E_HIP, "mfma sample launch failed");
+        if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
+        if ((rc = crag_launch_tau_select((const uint32_t*)ws->sample.p, P.sample_stride, qd_dev, B, P.M, (float*)ws->tau.p, st)))
+            return fail(CRAG_E_HIP, "tau_select launch failed");
+        a.row_end = h0->n_rows;
+        if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
+        if ((rc = crag_launch_scan_mfma(a, 1, st))) return fail(CRAG_E_HIP, "mfma filter launch failed");
+        if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+        h0->stats[5]++;
+    } else {
+        ScanArgs a;
+        a.groups = gd_dev;
+        a.n_groups = P.n_groups;
+        a.queries = q_dev;
+        a.dtype = h0->dtype;
+        a.chunks = h0->chunks;
+        a.metric = h0->metric;
+        a.tau = (const float*)ws->tau.p;
+        a.sample = (uint32_t*)ws->sample.p;
+        a.sample_stride = P.sample_stride;
+        a.cand = (unsigned long long*)ws->cand.p;
+        a.cnt = cnt;
+        if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
+        if ((rc = crag_launch_scan_gemv(a, 0, P.nq_template, P.blocks[0], st))) return fail(CRAG_E_HIP, "gemv sample launch failed");
+        if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
+        if ((rc = crag_launch_tau_select((const uint32_t*)ws->sample.p, P.sample_stride, qd_dev, B, P.M, (float*)ws->tau.p, st)))
+            return fail(CRAG_E_HIP, "tau_select launch failed");
+        if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
+        if ((rc = crag_launch_scan_gemv(a, 1, P.nq_template, P.blocks[1], st))) return fail(CRAG_E_HIP, "gemv filter launch failed");
+        if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+        h0->stats[6]++;
+    }
+    FinalizeArgs f;
+    f.qd = qd_dev;
+    f.queries = q_dev;
+    f.B = B;
+    f.dtype = h0->dtype;
+    f.dim = h0->dim;
+    f.dim_pad = h0->dim_pad;
+    f.metric = h0->metric;
+    f.M = P.M;
+    f.kc = P.kc;
+    f.cand = (const unsigned long long*)ws->cand.p;
+    f.cnt = cnt;
+    f.tau = (const float*)ws->tau.p;
+    f.trusted = 0;
+    f.qhash = (const unsigned long long*)qh_dev;
+    f.qhash_off = (const int*)qhoff_dev;
+    f.entries = entries_dev;
+    f.status = status;
+    if ((rc = crag_launch_finalize(f, st))) return fail(CRAG_E_HIP, "finalize launch failed");
+
+    // ---- verify: every query must carry an exactness certificate ----
+    std::vector<uint32_t> hst((size_t)B);
+    HIPCHK(hipMemcpyAsync(hst.data(), status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (prof) {
+        float ms0 = 0.f, ms1 = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms0, ws->ev[0], ws->ev[1]));
+        HIPCHK(hipEventElapsedTime(&ms1, ws->ev[2], ws->ev[3]));
+        std::lock_guard<std::mutex> lk(h0->prof_mu);
+        h0->prof[0] += ms0;
+        h0->prof[1] += ms1;
+        h0->prof[2] += 1.0;
+    }
+    h0->stats[0]++;
+    h0->stats[1] += B;
+    for (int b = 0; b < B; ++b) {
+        if (hst[(size_t)b] == CRAG_ST_OK) continue;
+        crag_index* h = hs[b];
+        h0->stats[2]++;
+        if (hst[(size_t)b] == CRAG_ST_UNCERTIFIED) h0->stats[3]++;
+        if (hst[(size_t)b] == CRAG_ST_OVERFLOW) h0->stats[4]++;
+        // exact fallback: canonical float32 distance of every row, radix-select the kc smallest keys
+        const long long n = h->n_rows;
+        const int kc = (int)std::min<long long>(P.kc, n);
+        if ((rc = ws->keys.ensure(sizeof(unsigned long long) * (size_t)std::max<long long>(n, 1)))) return rc;
+        if ((rc = ws->misc.ensure(4096))) return rc;
+        unsigned long long* keys = (unsigned long long*)ws->keys.p;
+        unsigned int* hist = (unsigned int*)ws->misc.p;
+        const void* qv = (const char*)q_dev + (size_t)b * h->dim_pad * h->esz;
+        if ((rc = crag_launch_exact_keys(&qd[(size_t)b], qv, h->dtype, h->dim, h->dim_pad, h->metric, keys, st)))
+            return fail(CRAG_E_HIP, "exact_keys launch failed");
+        unsigned long long prefix = 0, mask = 0;
+        unsigned int want = (unsigned int)kc;
+        for (int shift = 56; shift >= 0 && kc > 0; shift -= 8) {
+            unsigned int hh[256];
+            HIPCHK(hipMemsetAsync(hist, 0, 1024, st));
+            if ((rc = crag_launch_hist64(keys, n, prefix, mask, shift, hist, st))) return fail(CRAG_E_HIP, "hist64 launch failed");
+            HIPCHK(hipMemcpyAsync(hh, hist, 1024, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            unsigned int cum = 0;
+            int bin = 255;
+            for (int i = 0; i < 256; ++i) {
+                if (cum + hh[i] >= want) {
+                    bin = i;
+                    break;
+                }
+                cum += hh[i];
+            }
+            want -= cum;
+            prefix |= (unsigned long long)bin << shift;
+            mask |= 0xffull << shift;
+        }
+        unsigned long long* cq = (unsigned long long*)ws->cand.p + (size_t)b * CRAG_CAND_CAP;
+        HIPCHK(hipMemsetAsync(cnt + b, 0, 4, st));
+        if (kc > 0) {
+            if ((rc = crag_launch_gather_le(keys, n, prefix, cq, cnt + b, CRAG_CAND_CAP, st)))
+                return fail(CRAG_E_HIP, "gather launch failed");
+        }
+        FinalizeArgs g = f;
+        g.qd = qd_dev + b;
+        g.queries = qv;
+        g.B = 1;
+        g.M = std::max(kc, 1);
+        g.cand = cq;
+        g.cnt = cnt + b;
+        g.tau = (const float*)ws->tau.p + b;
+        g.trusted = 1;
+        g.qhash_off = qhoff_dev ? (const int*)qhoff_dev + b : nullptr;
+        g.entries = entries_dev + (size_t)b * P.kc;
+        g.status = status + b;
+        if ((rc = crag_launch_finalize(g, st))) return fail(CRAG_E_HIP, "fallback finalize launch failed");
+        uint32_t s2 = 1;
+        HIPCHK(hipMemcpyAsync(&s2, status + b, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (s2 != CRAG_ST_OK) return fail(CRAG_E_HIP, "exact fallback did not produce a certified result");
+    }
+    return 0;
+}
+
+int check_search_args(crag_index* const* hs, int B, int top_k) {
+    if (!hs || B <= 0 || top_k <= 0) return fail(CRAG_E_INVALID, "search: B and top_k must be positive");
+    if (top_k > CRAG_MAX_TOP_K) return fail(CRAG_E_LIMIT, "search: top_k exceeds CRAG_MAX_TOP_K");
+    crag_index* h0 = hs[0];
+    for (int b = 0; b < B; ++b) {
+        crag_index* h = hs[b];
+        if (!h) return fail(CRAG_E_INVALID, "search: null collection handle");
+        if (!h->finalized) return fail(CRAG_E_STATE, "search: collection not finalized");
+        if (h->dim != h0->dim || h->dtype != h0->dtype || h->metric != h0->metric || h->device != h0->device)
+            return fail(CRAG_E_INVALID, "search_multi: collections differ in dim/dtype/metric/device");
+    }
+    return 0;
+}
+
+// host queries (float32) -> device, index dtype, padded stride.  Returns device pointer in ws->q.
+int upload_queries(crag_index* h, const float* queries, int B, Workspace* ws, hipStream_t st, size_t pinned_off) {
+    const size_t bytes = (size_t)B * h->dim_pad * h->esz;
+    int rc;
+    if ((rc = ws->q.ensure(bytes))) return rc;
+    char* stage = (char*)ws->pinned + pinned_off;
+    memset(stage, 0, bytes);
+    for (int b = 0; b < B; ++b) {
+        const float* src = queries + (size_t)b * h->dim;
+        if (h->dtype == CRAG_F32) {
+            memcpy(stage + (size_t)b * h->dim_pad * 4, src, (size_t)h->dim * 4);
+        } else {
+            uint16_t* dst = (uint16_t*)(stage + (size_t)b * h->dim_pad * 2);
+            for (int d = 0; d < h->dim; ++d) dst[d] = f32_to_bf16(src[d]);
+        }
+    }
+    HIPCHK(hipMemcpyAsync(ws->q.p, stage, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+int symbol_hashes_host(const crag_index* h, const unsigned char* q, int64_t len, std::vector<uint64_t>& out) {
+    out.clear();
+    if (h->names.empty() || len <= 0) return 0;
+    const int maxlen = h->max_name_len;
+    for (int64_t i = 0; i < len; ++i) {
+        uint64_t hash = 1469598103934665603ull;
+        const int64_t lim = std::min<int64_t>(maxlen, len - i);
+        for (int64_t l = 1; l <= lim; ++l) {
+            hash ^= q[i + l - 1];
+            hash *= 1099511628211ull;
+            if (h->len_present[(size_t)l]) {
+                const uint64_t hh = hash ? hash : 1ull;
+                if (h->names.count(hh)) out.push_back(hh);
+            }
+        }
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    return 0;
+}
+
+int search_host(crag_index* const* hs, bool same, const float* queries, int B, int top_k, double symbol_boost,
+                const char* qtext, const int64_t* qtext_off, int64_t* out_ids, double* out_scores, float* out_dist,
+                int32_t* out_counts) {
+    int rc = check_search_args(hs, B, top_k);
+    if (rc) return rc;
+    if (!queries || !out_ids || !out_scores || !out_dist || !out_counts)
+        return fail(CRAG_E_INVALID, "search: null buffer");
+    crag_index* h0 = hs[0];
+    HIPCHK(hipSetDevice(h0->device));
+    WsGuard guard(h0->device);
+    Workspace* ws = guard.w;
+    if (!ws) return fail(CRAG_E_HIP, "could not create a HIP stream");
+    hipStream_t st = ws->stream;
+    const int kc = 2 * top_k;
+
+    // symbol hashes per query (R3)
+    std::vector<uint64_t> all_h;
+    std::vector<int32_t> off((size_t)B + 1, 0);
+    bool any_hash = false;
+    if (qtext && qtext_off) {
+        std::vector<uint64_t> one;
+        for (int b = 0; b < B; ++b) {
+            symbol_hashes_host(hs[b], (const unsigned char*)qtext + qtext_off[b], qtext_off[b + 1] - qtext_off[b], one);
+            all_h.insert(all_h.end(), one.begin(), one.end());
+            off[(size_t)b + 1] = (int32_t)all_h.size();
+        }
+        any_hash = true;
+    }
+    const size_t qbytes = (size_t)B * h0->dim_pad * h0->esz;
+    const size_t desc_reserve = (sizeof(QueryDesc) + sizeof(GroupDesc)) * (size_t)B;
+    const size_t hash_bytes = all_h.size() * 8 + off.size() * 4 + 16;
+    const size_t out_bytes = (size_t)B * top_k * (8 + 8 + 4) + (size_t)B * 4;
+    if ((rc = ws->ensure_pinned(desc_reserve + qbytes + hash_bytes + out_bytes + 64))) return rc;
+    // pinned layout: [desc | queries | hashes+offsets | outputs]
+    const size_t q_off = (desc_reserve + 15) / 16 * 16;
+    const size_t h_off = (q_off + qbytes + 15) / 16 * 16;
+    const size_t o_off = (h_off + hash_bytes + 15) / 16 * 16;
+    if ((rc = upload_queries(h0, queries, B, ws, st, q_off))) return rc;
+    const uint64_t* qh_dev = nullptr;
+    const int32_t* qo_dev = nullptr;
+    if (any_hash) {
+        if ((rc = ws->qhash.ensure(hash_bytes))) return rc;
+        char* stage = (char*)ws->pinned + h_off;
+        memcpy(stage, off.data(), off.size() * 4);
+        const size_t hoff = (off.size() * 4 + 7) / 8 * 8;
+        if (!all_h.empty()) memcpy(stage + hoff, all_h.data(), all_h.size() * 8);
+        HIPCHK(hipMemcpyAsync(ws->qhash.p, stage, hoff + all_h.size() * 8, hipMemcpyHostToDevice, st));
+        qo_dev = (const int32_t*)ws->qhash.p;
+        qh_dev = (const uint64_t*)((char*)ws->qhash.p + hoff);
+    }
+    if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * kc))) return rc;
+    if ((rc = ws->out.ensure(out_bytes))) return rc;
+    rc = search_entries(hs, same, ws->q.p, B, top_k, qh_dev, qo_dev, (CragEntry*)ws->entries.p, ws, st);
+    if (rc) return rc;
+    char* o = (char*)ws->out.p;
+    long long* d_ids = (long long*)o;
+    double* d_sc = (double*)(o + (size_t)B * top_k * 8);
+    float* d_di = (float*)(o + (size_t)B * top_k * 16);
+    int* d_cn = (int*)(o + (size_t)B * top_k * 20);
+    if ((rc = crag_launch_merge_rerank((const CragEntry*)ws->entries.p, 1, B, kc, top_k, symbol_boost, d_ids, d_sc, d_di, d_cn, st)))
+        return fail(CRAG_E_HIP, "merge_rerank launch failed");
+    char* ho = (char*)ws->pinned + o_off;
+    HIPCHK(hipMemcpyAsync(ho, o, out_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(out_ids, ho, (size_t)B * top_k * 8);
+    memcpy(out_scores, ho + (size_t)B * top_k * 8, (size_t)B * top_k * 8);
+    memcpy(out_dist, ho + (size_t)B * top_k * 16, (size_t)B * top_k * 4);
+    memcpy(out_counts, ho + (size_t)B * top_k * 20, (size_t)B * 4);
+    return 0;
+}
+
+// device queries [B][dim] in index dtype -> pointer with stride dim_pad (copy only when padding is needed)
+int stage_device_queries(crag_index* h, const void* queries_dev, int B, Workspace* ws, hipStream_t st, const void** out) {
+    if (h->dim == h->dim_pad) {
+        *out = queries_dev;
+        return 0;
+    }
+    const size_t bytes = (size_t)B * h->dim_pad * h->esz;
+    int rc;
+    if ((rc = ws->q.ensure(bytes))) return rc;
+    HIPCHK(hipMemsetAsync(ws->q.p, 0, bytes, st));
+    HIPCHK(hipMemcpy2DAsync(ws->q.p, (size_t)h->dim_pad * h->esz, queries_dev, (size_t)h->dim * h->esz,
+                            (size_t)h->dim * h->esz, (size_t)B, hipMemcpyDeviceToDevice, st));
+    *out = ws->q.p;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crag_version(void) { return 100; }
+const char* crag_last_error(void) { return g_err.c_str(); }
+int crag_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(CRAG_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int crag_index_create(int dim, int dtype, int metric, int device, crag_index** out) {
+    if (!out) return fail(CRAG_E_INVALID, "crag_index_create: out is NULL");
+    *out = nullptr;
+    if (dim <= 0 || (dtype != CRAG_F32 && dtype != CRAG_BF16) || (metric != CRAG_L2 && metric != CRAG_IP))
+        return fail(CRAG_E_INVALID, "crag_index_create: bad dim/dtype/metric");
+    const size_t esz = dtype == CRAG_F32 ? 4 : 2;
+    const size_t chunks_needed = ((size_t)dim * esz + 15) / 16;
+    int chunks = 0;
+    for (int c : kChunkSizes)
+        if ((size_t)c >= chunks_needed) {
+            chunks = c;
+            break;
+        }
+    if (!chunks) return fail(CRAG_E_LIMIT, "crag_index_create: rows longer than 4096 bytes are not supported");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CRAG_E_INVALID, "crag_index_create: no such device");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(CRAG_E_HIP, std::string("crag_index_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    crag_index* h = new crag_index();
+    h->dim = dim;
+    h->dtype = dtype;
+    h->metric = metric;
+    h->device = device;
+    h->esz = esz;
+    h->chunks = chunks;
+    h->dim_pad = (int)((size_t)chunks * 16 / esz);
+    h->len_present.assign(65536 + 1, 0);
+    *out = h;
+    return 0;
+}
+
+int crag_index_destroy(crag_index* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->owns_rows && h->rows) (void)hipFree(h->rows);
+    if (h->xnorm) (void)hipFree(h->xnorm);
+    if (h->owns_meta) {
+        if (h->name_hash) (void)hipFree(h->name_hash);
+        if (h->path_class) (void)hipFree(h->path_class);
+    }
+    delete h;
+    return 0;
+}
+
+int64_t crag_index_size(const crag_index* h) { return h ? h->n_rows : 0; }
+int crag_index_dim_pad(const crag_index* h) { return h ? h->dim_pad : 0; }
+int crag_index_set_id_base(crag_index* h, int64_t id_base) {
+    if (!h) return fail(CRAG_E_INVALID, "null handle");
+    h->id_base = id_base;
+    return 0;
+}
+
+int crag_index_set_symbols(crag_index* h, const uint64_t* hashes, const uint16_t* lens, int64_t n) {
+    if (!h || n < 0 || (n > 0 && (!hashes || !lens))) return fail(CRAG_E_INVALID, "crag_index_set_symbols: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        if (hashes[i] == 0 || lens[i] == 0) continue;
+        h->names.insert(hashes[i]);
+        h->len_present[lens[i]] = 1;
+        h->max_name_len = std::max<int>(h->max_name_len, lens[i]);
+    }
+    return 0;
+}
+
+int crag_index_add(crag_index* h, const void* rows, int64_t n, const uint64_t* name_hash, const uint16_t* name_len,
+                   const uint8_t* path_class) {
+    int rc = add_common(h, rows, n, name_hash, path_class, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    if (name_hash && name_len) return crag_index_set_symbols(h, name_hash, name_len, n);
+    return 0;
+}
+
+int crag_index_add_device(crag_index* h, const void* rows_dev, int64_t n, const uint64_t* name_hash_dev,
+                          const uint8_t* path_class_dev) {
+    return add_common(h, rows_dev, n, name_hash_dev, path_class_dev, hipMemcpyDeviceToDevice);
+}
+
+int crag_index_attach_device(crag_index* h, const void* rows_dev, int64_t n, const uint64_t* name_hash_dev,
+                             const uint8_t* path_class_dev) {
+    if (!h || !rows_dev || n < 0) return fail(CRAG_E_INVALID, "crag_index_attach_device: bad arguments");
+    if (h->n_rows != 0) return fail(CRAG_E_STATE, "crag_index_attach_device: collection already holds rows");
+    if (h->dim != h->dim_pad) return fail(CRAG_E_INVALID, "crag_index_attach_device: dim must equal crag_index_dim_pad");
+    if (((uintptr_t)rows_dev) & 15) return fail(CRAG_E_INVALID, "crag_index_attach_device: rows must be 16-byte aligned");
+    h->rows = const_cast<void*>(rows_dev);
+    h->owns_rows = false;
+    h->attached = true;
+    h->name_hash = const_cast<uint64_t*>(name_hash_dev);
+    h->path_class = const_cast<uint8_t*>(path_class_dev);
+    h->owns_meta = false;
+    h->n_rows = n;
+    h->cap_rows = n;
+    h->finalized = false;
+    return 0;
+}
+
+int crag_index_finalize(crag_index* h) {
+    if (!h) return fail(CRAG_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->xnorm) (void)hipFree(h->xnorm);
+    h->xnorm = nullptr;
+    h->max_xnorm = 0.f;
+    // padded by 256 floats: the MFMA epilogue reads |x|^2 for whole 128-row tiles
+    const size_t nx = (size_t)std::max<int64_t>(h->n_rows, 1) + 256;
+    HIPCHK(hipMalloc((void**)&h->xnorm, sizeof(float) * (nx + 4)));
+    HIPCHK(hipMemset(h->xnorm, 0, sizeof(float) * (nx + 4)));
+    float* mx = h->xnorm + nx;
+    if (h->n_rows) {
+        int rc = crag_launch_row_norms(h->rows, h->dtype, h->dim_pad, h->n_rows, h->xnorm, mx, nullptr);
+        if (rc) return fail(CRAG_E_HIP, "row_norms launch failed");
+    }
+    HIPCHK(hipMemcpy(&h->max_xnorm, mx, 4, hipMemcpyDeviceToHost));
+    h->finalized = true;
+    return 0;
+}
+
+uint64_t crag_hash_name(const char* utf8, int64_t len) {
+    if (!utf8 || len <= 0) return 0;
+    return fnv1a((const unsigned char*)utf8, len);
+}
+void crag_hash_names(const char* buf, const int64_t* off, int64_t n, uint64_t* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = crag_hash_name(buf + off[i], off[i + 1] - off[i]);
+}
+
+int crag_symbol_hashes(const crag_index* h, const char* q_lower_utf8, int64_t len, uint64_t* out, int cap) {
+    if (!h || (len > 0 && !q_lower_utf8) || (cap > 0 && !out)) return fail(CRAG_E_INVALID, "crag_symbol_hashes: bad arguments");
+    std::vector<uint64_t> v;
+    symbol_hashes_host(h, (const unsigned char*)q_lower_utf8, len, v);
+    const int n = (int)std::min<size_t>(v.size(), (size_t)std::max(cap, 0));
+    for (int i = 0; i < n; ++i) out[i] = v[(size_t)i];
+    return n;
+}
+
+int crag_search(crag_index* h, const float* queries, int B, int top_k, double symbol_boost, const char* qtext,
+                const int64_t* qtext_off, int64_t* out_ids, double* out_scores, float* out_dist,
+                int32_t* out_counts) {
+    if (!h || B <= 0) return fail(CRAG_E_INVALID, "crag_search: bad arguments");
+    std::vector<crag_index*> hs((size_t)B, h);
+    return search_host(hs.data(), true, queries, B, top_k, symbol_boost, qtext, qtext_off, out_ids, out_scores, out_dist, out_counts);
+}
+
+int crag_search_multi(crag_index* const* hs, const float* queries, int B, int top_k, double symbol_boost,
+                      const char* qtext, const int64_t* qtext_off, int64_t* out_ids, double* out_scores,
+                      float* out_dist, int32_t* out_counts) {
+    if (!hs || B <= 0) return fail(CRAG_E_INVALID, "crag_search_multi: bad arguments");
+    bool same = true;
+    for (int b = 1; b < B; ++b) same = same && hs[b] == hs[0];
+    return search_host(hs, same, queries, B, top_k, symbol_boost, qtext, qtext_off, out_ids, out_scores, out_dist, out_counts);
+}
+
+int crag_search_local_device(crag_index* h, const void* queries_dev, int B, int top_k, const uint64_t* q_hashes_dev,
+                             const int32_t* q_hash_off_dev, void* entries_dev, void* stream) {
+    if (!h || !queries_dev || !entries_dev) return fail(CRAG_E_INVALID, "crag_search_local_device: bad arguments");
+    std::vector<crag_index*> hs((size_t)std::max(B, 1), h);
+    int rc = check_search_args(hs.data(), B, top_k);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    WsGuard guard(h->device);
+    if (!guard.w) return fail(CRAG_E_HIP, "could not create a HIP stream");
+    hipStream_t st = (hipStream_t)stream;
+    const void* q = nullptr;
+    if ((rc = stage_device_queries(h, queries_dev, B, guard.w, st, &q))) return rc;
+    return search_entries(hs.data(), true, q, B, top_k, q_hashes_dev, q_hash_off_dev, (CragEntry*)entries_dev, guard.w, st);
+}
+
+int crag_merge_rerank_device(int device, const void* entries_dev, int G, int B, int top_k, double symbol_boost,
+                             int64_t* out_ids_dev, double* out_scores_dev, float* out_dist_dev,
+                             int32_t* out_counts_dev, void* stream) {
+    if (!entries_dev || G <= 0 || B <= 0 || top_k <= 0 || top_k > CRAG_MAX_TOP_K)
+        return fail(CRAG_E_INVALID, "crag_merge_rerank_device: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    int rc = crag_launch_merge_rerank((const CragEntry*)entries_dev, G, B, 2 * top_k, top_k, symbol_boost,
+                                      (long long*)out_ids_dev, out_scores_dev, out_dist_dev, out_counts_dev,
+                                      (hipStream_t)stream);
+    if (rc == -2) return fail(CRAG_E_LIMIT, "crag_merge_rerank_device: G * 2*top_k too large for one workgroup");
+    if (rc) return fail(CRAG_E_HIP, "merge_rerank launch failed");
+    return 0;
+}
+
+int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k, double symbol_boost,
+                       const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
+                       double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream) {
+    if (!h || !queries_dev || !out_ids_dev || !out_scores_dev || !out_dist_dev || !out_counts_dev)
+        return fail(CRAG_E_INVALID, "crag_search_device: bad arguments");
+    std::vector<crag_index*> hs((size_t)std::max(B, 1), h);
+    int rc = check_search_args(hs.data(), B, top_k);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    WsGuard guard(h->device);
+    if (!guard.w) return fail(CRAG_E_HIP, "could not create a HIP stream");
+    Workspace* ws = guard.w;
+    hipStream_t st = (hipStream_t)stream;
+    const void* q = nullptr;
+    if ((rc = stage_device_queries(h, queries_dev, B, ws, st, &q))) return rc;
+    if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * 2 * top_k))) return rc;
+    rc = search_entries(hs.data(), true, q, B, top_k, q_hashes_dev, q_hash_off_dev, (CragEntry*)ws->entries.p, ws, st);
+    if (rc) return rc;
+    rc = crag_launch_merge_rerank((const CragEntry*)ws->entries.p, 1, B, 2 * top_k, top_k, symbol_boost,
+                                  (long long*)out_ids_dev, out_scores_dev, out_dist_dev, out_counts_dev, st);
+    if (rc) return fail(CRAG_E_HIP, "merge_rerank launch failed");
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int crag_stats(crag_index* h, int64_t* out7, int reset) {
+    if (!h || !out7) return fail(CRAG_E_INVALID, "crag_stats: bad arguments");
+    for (int i = 0; i < 7; ++i) {
+        out7[i] = h->stats[i];
+        if (reset) h->stats[i] = 0;
+    }
+    return 0;
+}
+
+int crag_set_profiling(crag_index* h, int on) {
+    if (!h) return fail(CRAG_E_INVALID, "crag_set_profiling: null handle");
+    h->profiling = on ? 1 : 0;
+    return 0;
+}
+
+int crag_get_profile(crag_index* h, double* out3, int reset) {
+    if (!h || !out3) return fail(CRAG_E_INVALID, "crag_get_profile: bad arguments");
+    std::lock_guard<std::mutex> lk(h->prof_mu);
+    for (int i = 0; i < 3; ++i) {
+        out3[i] = h->prof[i];
+        if (reset) h->prof[i] = 0.0;
+    }
+    return 0;
+}
+
+int crag_set_path(crag_index* h, int path) {
+    if (!h || path < 0 || path > 2) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
+    h->force_path = path;
+    return 0;
+}
+
+}  // extern "C"

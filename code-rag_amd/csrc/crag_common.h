@@ -1,0 +1,137 @@
+// Shared host/device definitions of the coderag-hip retrieval scoring library (gfx950 only).
+//
+// The path this library replaces: /root/reference/retriever/hybrid_search.py:42-125
+// (HybridSearcher.search) -- the Chroma `col.query` k-NN (:60-64) plus the rerank (:69-125).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CRAG_F32 0
+#define CRAG_BF16 1
+#define CRAG_L2 0
+#define CRAG_IP 1
+
+// status words written per query by k_finalize
+#define CRAG_ST_OK 0u
+#define CRAG_ST_UNCERTIFIED 1u  // exactness certificate failed -> exact fallback scan
+#define CRAG_ST_OVERFLOW 2u     // candidate buffer overflowed  -> exact fallback scan
+
+// flags of a candidate entry
+#define CRAG_FLAG_CLASS_MASK 3u  // 0 neutral, 1 penalised (x0.1), 2 boosted (x1.2): hybrid_search.py:105-111
+#define CRAG_FLAG_SYMBOL 4u      // lowered chunk name is a substring of the lowered query (:114)
+
+// One candidate as it crosses GPUs (16 B): the exact float32 distance Chroma would hand to
+// hybrid_search.py:71, the global row id, and the query-independent/-dependent boost bits.
+struct CragEntry {
+    float dist;
+    uint32_t flags;
+    long long id;
+};
+
+// Queries that share one row range and are scanned together (GEMV regime: up to 8).
+struct GroupDesc {
+    const void* rows;
+    const float* xnorm;
+    long long n_rows;
+    long long n_sample;  // rows [0, n_sample) form the dense threshold sample
+    int q_first, nq;
+    int blk_first[2];  // [0] sample pass, [1] filter pass
+    int n_blk[2];
+};
+
+// Everything the per-query kernels need (one per query of the batch).
+struct QueryDesc {
+    const void* rows;
+    const float* xnorm;
+    const unsigned long long* name_hash;  // may be null
+    const unsigned char* path_class;      // may be null
+    long long n_rows;
+    long long n_sample;
+    long long id_base;
+    float max_xnorm;
+    int pad;
+};
+
+// ---------------------------------------------------------------------------------------
+// order-preserving float <-> uint32 key
+__host__ __device__ inline uint32_t crag_fkey(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float crag_fkey_inv(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+// geometry of the streamed row layout: C = 16-byte chunks per (padded) row
+__host__ __device__ constexpr int crag_gcd(int a, int b) { return b == 0 ? a : crag_gcd(b, a % b); }
+__host__ __device__ constexpr int crag_lcm(int a, int b) { return a / crag_gcd(a, b) * b; }
+
+// candidate buffer and sort limits of the select stage
+#define CRAG_CAND_CAP 8192
+#define CRAG_MAX_M 512      // rescored candidates per query (2*top_k + slack) upper limit
+#define CRAG_MAX_KC 400     // 2*top_k upper limit
+#define CRAG_MAX_GROUP_Q 8  // queries per GEMV group
+
+// launchers implemented in the .hip files ------------------------------------------------
+struct ScanArgs {
+    const GroupDesc* groups;
+    int n_groups;
+    const void* queries;  // [B][dim_pad], index dtype
+    int dtype;
+    int chunks;  // C
+    int metric;
+    const float* tau;         // [B]
+    uint32_t* sample;         // [B][sample_stride] ordered-float keys
+    long long sample_stride;
+    unsigned long long* cand;  // [B][CRAG_CAND_CAP]
+    uint32_t* cnt;             // [B]
+};
+int crag_launch_scan_gemv(const ScanArgs& a, int mode, int nq_template, int total_blocks, hipStream_t s);
+bool crag_gemv_supported(int dtype, int chunks);
+
+struct MfmaArgs {
+    const void* rows;
+    const float* xnorm;
+    long long n_rows;   // rows scanned by this launch: [row_begin, row_end)
+    long long row_begin, row_end;
+    const void* queries;  // [Bpad][dim_pad] bf16
+    int n_queries;        // real queries
+    int dim_pad;
+    int metric;
+    const float* tau;
+    uint32_t* sample;
+    long long sample_stride;
+    unsigned long long* cand;
+    uint32_t* cnt;
+};
+int crag_launch_scan_mfma(const MfmaArgs& a, int mode, hipStream_t s);
+
+int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n, float* xnorm, float* max_out,
+                          hipStream_t s);
+int crag_launch_tau_select(const uint32_t* sample, long long sample_stride, const QueryDesc* qd, int B, int M,
+                           float* tau, hipStream_t s);
+struct FinalizeArgs {
+    const QueryDesc* qd;
+    const void* queries;
+    int B, dtype, dim, dim_pad, metric;
+    int M, kc;
+    const unsigned long long* cand;
+    const uint32_t* cnt;
+    const float* tau;                 // [B] filter thresholds (certificate bound when the buffer is exhausted)
+    int trusted;                      // 1: keys are already exact (fallback path) -> skip the certificate
+    const unsigned long long* qhash;  // sorted per query
+    const int* qhash_off;             // [B+1], may be null
+    CragEntry* entries;               // [B][kc]
+    uint32_t* status;                 // [B]
+};
+int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s);
+int crag_launch_merge_rerank(const CragEntry* entries, int G, int B, int kc, int top_k, double symbol_boost,
+                             long long* out_ids, double* out_scores, float* out_dist, int* out_counts,
+                             hipStream_t s);
+int crag_launch_exact_keys(const QueryDesc* qd_host, const void* query, int dtype, int dim, int dim_pad, int metric,
+                           unsigned long long* keys, hipStream_t s);
+int crag_launch_hist64(const unsigned long long* keys, long long n, unsigned long long prefix,
+                       unsigned long long mask, int shift, unsigned int* hist256, hipStream_t s);
+int crag_launch_gather_le(const unsigned long long* keys, long long n, unsigned long long thr,
+                          unsigned long long* out, unsigned int* out_cnt, unsigned int cap, hipStream_t s);

@@ -1,0 +1,509 @@
+// K3 + R1..R5: threshold selection, candidate selection, exact re-scoring, merge and rerank.
+//
+//   k_row_norms     |x|^2 per row (fp32) + max, once per collection
+//   k_tau_select    per query: M-th smallest score of the dense sample -> filter threshold tau
+//   k_finalize      per query: sort the filtered candidates by (score, row), re-score the M best in
+//                   the canonical fp64 order (bit-identical to oracle/oracle.py), certify that no
+//                   row outside the re-scored set can enter the 2*top_k nearest, emit CragEntry[kc]
+//   k_merge_rerank  per query: merge G shards' entries by (float32 distance, id), then
+//                   hybrid_search.py:82-125 verbatim in fp64 (base score, path/symbol boost,
+//                   strict > 0.01 filter, stable descending sort, truncate to top_k)
+//   k_exact_keys / k_hist64 / k_gather_le   the exact fallback scan (rare; correctness only)
+#include "crag_common.h"
+
+namespace {
+
+__device__ __forceinline__ double load_elem_f64(const void* p, int dtype, long long idx) {
+    if (dtype == CRAG_F32) return (double)((const float*)p)[idx];
+    uint32_t u = ((uint32_t)((const unsigned short*)p)[idx]) << 16;
+    return (double)__builtin_bit_cast(float, u);
+}
+
+// ----------------------------------------------------------------------------------------
+// row norms: one wave per row, 16-byte coalesced loads, fp64 accumulation
+__global__ __launch_bounds__(256) void k_row_norms(const uint4* __restrict__ rows, int dtype, int chunks,
+                                                   long long n, float* __restrict__ xnorm,
+                                                   unsigned int* __restrict__ max_bits) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * 4;
+    float wmax = 0.f;
+    for (long long r = wave0; r < n; r += n_waves) {
+        double acc = 0.0;
+        for (int c = lane; c < chunks; c += 64) {
+            const uint4 v = rows[r * chunks + c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (dtype == CRAG_F32) {
+                    const double f = (double)__builtin_bit_cast(float, w[k]);
+                    acc += f * f;
+                } else {
+                    const double lo = (double)__builtin_bit_cast(float, w[k] << 16);
+                    const double hi = (double)__builtin_bit_cast(float, w[k] & 0xffff0000u);
+                    acc += lo * lo;
+                    acc += hi * hi;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        const float f = (float)acc;
+        if (lane == 0) xnorm[r] = f;
+        wmax = fmaxf(wmax, f);
+    }
+    if (lane == 0) atomicMax(max_bits, __builtin_bit_cast(unsigned int, wmax));
+}
+
+// ----------------------------------------------------------------------------------------
+// block-wide helpers (1024 threads)
+__device__ __forceinline__ void find_bin_256(unsigned int* hist, unsigned int* sh, unsigned int want) {
+    // hist[256] in LDS; finds bin b with prefix(b) < want <= prefix(b)+hist[b]; writes sh[0]=b, sh[1]=want-prefix(b)
+    const int t = threadIdx.x;
+    __shared__ unsigned int wsum[4];
+    unsigned int v = 0, incl = 0;
+    if (t < 256) {
+        v = hist[t];
+        incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off);
+            if ((t & 63) >= off) incl += o;
+        }
+        if ((t & 63) == 63) wsum[t >> 6] = incl;
+    }
+    __syncthreads();
+    if (t < 256) {
+        unsigned int base = 0;
+        for (int k = 0; k < (t >> 6); ++k) base += wsum[k];
+        incl += base;
+        const unsigned int excl = incl - v;
+        if (v != 0 && excl < want && want <= incl) {
+            sh[0] = (unsigned int)t;
+            sh[1] = want - excl;
+        }
+    }
+    __syncthreads();
+}
+
+// per query: tau = M-th smallest ordered key among the first n_sample scores
+__global__ __launch_bounds__(1024) void k_tau_select(const uint32_t* __restrict__ sample, long long stride,
+                                                     const QueryDesc* __restrict__ qd, int M,
+                                                     float* __restrict__ tau) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sh[2];
+    const int q = blockIdx.x;
+    const long long n = qd[q].n_sample;
+    if (n <= (long long)M) {  // every row is a candidate
+        if (threadIdx.x == 0) tau[q] = __builtin_inff();
+        return;
+    }
+    const uint32_t* __restrict__ keys = sample + (long long)q * stride;
+    uint32_t prefix = 0, mask = 0;
+    unsigned int want = (unsigned int)M;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (long long i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t k = keys[i];
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        find_bin_256(hist, sh, want);
+        prefix |= sh[0] << shift;
+        mask |= 255u << shift;
+        want = sh[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tau[q] = crag_fkey_inv(prefix);
+}
+
+// ----------------------------------------------------------------------------------------
+// bitonic sort of P (power of two) 64-bit keys in LDS, ascending, by all threads of the block
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* s, int P) {
+    const int T = blockDim.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < (P >> 1); i += T) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int b = a | j;
+                const bool up = (a & k) == 0;
+                const unsigned long long x = s[a], y = s[b];
+                if ((x > y) == up) {
+                    s[a] = y;
+                    s[b] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// canonical fp64 partial sum of lane j (elements d = j, j+8, ...), oracle/oracle.py order
+__device__ __forceinline__ double canon_lane(const void* row, const void* q, int dtype, int dim, int j, int metric,
+                                             long long row_off) {
+    double acc = 0.0;
+    for (int d = j; d < dim; d += 8) {
+        const double a = load_elem_f64(q, dtype, d);
+        const double b = load_elem_f64(row, dtype, row_off + d);
+        double p;
+        if (metric == CRAG_L2) {
+            const double t = __dsub_rn(a, b);
+            p = __dmul_rn(t, t);
+        } else {
+            p = __dmul_rn(a, b);
+        }
+        acc = __dadd_rn(acc, p);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ double combine8(double acc) {
+    // ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)); IEEE addition commutes, so all 8 lanes agree
+    acc = __dadd_rn(acc, __shfl_xor(acc, 1));
+    acc = __dadd_rn(acc, __shfl_xor(acc, 2));
+    acc = __dadd_rn(acc, __shfl_xor(acc, 4));
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* skeys = (unsigned long long*)smem;                            // [CRAG_CAND_CAP]
+    unsigned long long* ekeys = skeys + CRAG_CAND_CAP;                                // [CRAG_MAX_M]
+    double* red = (double*)(ekeys + CRAG_MAX_M);                                      // [16]
+    const int q = blockIdx.x;
+    const QueryDesc D = a.qd[q];
+    const int tid = threadIdx.x;
+    const unsigned int raw_cnt = a.cnt[q];
+    unsigned int status = CRAG_ST_OK;
+    if (raw_cnt > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
+    const int c = raw_cnt < CRAG_CAND_CAP ? (int)raw_cnt : CRAG_CAND_CAP;
+    int P = 64;
+    while (P < c) P <<= 1;
+    const unsigned long long* __restrict__ cq = a.cand + (long long)q * CRAG_CAND_CAP;
+    for (int i = tid; i < P; i += blockDim.x) skeys[i] = i < c ? cq[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_u64(skeys, P);
+
+    const int m = c < a.M ? c : a.M;  // candidates re-scored exactly
+    const size_t esz = a.dtype == CRAG_F32 ? 4 : 2;
+    const void* qv = (const char*)a.queries + (size_t)q * a.dim_pad * esz;
+
+    // |q|^2 in fp64 (error bound only)
+    {
+        double part = 0.0;
+        for (int d = tid; d < a.dim; d += blockDim.x) {
+            const double v = load_elem_f64(qv, a.dtype, d);
+            part += v * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+            red[0] = s;
+        }
+        __syncthreads();
+    }
+    const double qn = red[0];
+
+    // exact re-scoring: 8 lanes per candidate
+    for (int base = 0; base < m; base += (int)(blockDim.x >> 3)) {
+        const int i = base + (tid >> 3);
+        const int j = tid & 7;
+        double acc = 0.0;
+        uint32_t row = 0;
+        if (i < m) {
+            row = (uint32_t)(skeys[i] & 0xffffffffull);
+            acc = canon_lane(D.rows, qv, a.dtype, a.dim, j, a.metric, (long long)row * a.dim_pad);
+        }
+        acc = combine8(acc);
+        if (i < m && j == 0) {
+            const double dist = a.metric == CRAG_L2 ? acc : __dsub_rn(1.0, acc);
+            ekeys[i] = ((unsigned long long)crag_fkey((float)dist) << 32) | row;
+        }
+    }
+    __syncthreads();
+
+    // rank the m exact keys by counting (keys are unique: the row id is part of the key)
+    const int kc_valid = m < a.kc ? m : a.kc;
+    CragEntry* out = a.entries + (long long)q * a.kc;
+    __shared__ unsigned int kth_bits;
+    for (int i = tid; i < m; i += blockDim.x) {
+        const unsigned long long k = ekeys[i];
+        int rank = 0;
+        for (int t = 0; t < m; ++t) rank += ekeys[t] < k;
+        if (rank < a.kc) {
+            const uint32_t row = (uint32_t)(k & 0xffffffffull);
+            uint32_t flags = 0;
+            if (D.path_class) flags |= (uint32_t)D.path_class[row] & CRAG_FLAG_CLASS_MASK;
+            if (D.name_hash && a.qhash_off) {
+                const unsigned long long h = D.name_hash[row];
+                int lo = a.qhash_off[q], hi = a.qhash_off[q + 1];
+                if (h != 0ull) {
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const unsigned long long v = a.qhash[mid];
+                        if (v == h) {
+                            flags |= CRAG_FLAG_SYMBOL;
+                            break;
+                        }
+                        if (v < h) lo = mid + 1; else hi = mid;
+                    }
+                }
+            }
+            CragEntry e;
+            e.dist = crag_fkey_inv((uint32_t)(k >> 32));
+            e.flags = flags;
+            e.id = D.id_base + (long long)row;
+            out[rank] = e;
+            if (rank == kc_valid - 1) kth_bits = (uint32_t)(k >> 32);
+        }
+    }
+    for (int i = kc_valid + tid; i < a.kc; i += blockDim.x) {
+        CragEntry e;
+        e.dist = __builtin_inff();
+        e.flags = 0;
+        e.id = 0x7fffffffffffffffll;
+        out[i] = e;
+    }
+    __syncthreads();
+
+    // exactness certificate.  Every row that was NOT re-scored has approximate score >= s_M: the
+    // buffer is sorted, so the remaining candidates start at skeys[m], and rows outside the buffer
+    // have s > tau >= every buffered score (s_M = tau when the whole buffer was re-scored).  Its exact distance is therefore at least
+    // s_M + offset - eps.  If the kc-th exact float32 distance is strictly below the float32
+    // rounding of that bound, no such row can enter (or tie into) the kc nearest.
+    if (tid == 0) {
+        if (!a.trusted && status == CRAG_ST_OK && (long long)m < D.n_rows && kc_valid > 0) {
+            // tightest known lower bound on the approximate score of every row not re-scored
+            const double sM = m < c ? (double)crag_fkey_inv((uint32_t)(skeys[m] >> 32)) : (double)a.tau[q];
+            const double u = 5.9604644775390625e-08;  // 2^-24
+            const double X = (double)D.max_xnorm;
+            const double qx = sqrt(qn * X);
+            double eps, lb;
+            if (a.metric == CRAG_L2) {
+                eps = 2.0 * u * (2.0 * (double)(a.dim_pad + 4) * qx + 3.0 * X + 1e-30);
+                lb = sM + qn - eps - 1e-12 * (qn + X);
+            } else {
+                eps = 2.0 * u * ((double)(a.dim_pad + 4) * qx + 1e-30);
+                lb = 1.0 + sM - eps - 1e-12 * (1.0 + qx);
+            }
+            float lbf = (float)lb;
+            if ((double)lbf > lb) lbf = nextafterf(lbf, -__builtin_inff());
+            const float dk = crag_fkey_inv(kth_bits);
+            if (!(dk < lbf)) status = CRAG_ST_UNCERTIFIED;
+        }
+        a.status[q] = status;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge_rerank(const CragEntry* __restrict__ entries, int G, int B, int kc,
+                                                      int top_k, double symbol_boost, long long* __restrict__ out_ids,
+                                                      double* __restrict__ out_scores, float* __restrict__ out_dist,
+                                                      int* __restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = G * kc;
+    long long* ids = (long long*)smem;             // [n]
+    double* score = (double*)(ids + n);            // [kc]
+    uint32_t* fk = (uint32_t*)(score + kc);        // [n]
+    uint32_t* fl = fk + n;                         // [n]
+    int* sel = (int*)(fl + n);                     // [kc]   position in [0,n) of the j-th nearest
+    int* keep = sel + kc;                          // [kc]
+    __shared__ int n_valid, n_keep;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        n_valid = 0;
+        n_keep = 0;
+    }
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int g = i / kc, j = i - g * kc;
+        const CragEntry e = entries[((long long)g * B + q) * kc + j];
+        ids[i] = e.id;
+        fk[i] = crag_fkey(e.dist);
+        fl[i] = e.flags;
+    }
+    __syncthreads();
+    // the kc nearest by (float32 distance, id): rank by counting
+    for (int i = tid; i < n; i += blockDim.x) {
+        const long long id = ids[i];
+        if (id == 0x7fffffffffffffffll) continue;
+        const uint32_t k = fk[i];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const uint32_t kt = fk[t];
+            rank += (kt < k) || (kt == k && ids[t] < id);
+        }
+        if (rank < kc) {
+            sel[rank] = i;
+            atomicAdd(&n_valid, 1);
+        }
+    }
+    __syncthreads();
+    const int nv = n_valid;  // = min(kc, number of real entries)
+    // R1..R4: hybrid_search.py:82,99-121
+    for (int j = tid; j < nv; j += blockDim.x) {
+        const int i = sel[j];
+        const double dist = (double)crag_fkey_inv(fk[i]);
+        const double base = __ddiv_rn(1.0, __dadd_rn(1.0, dist));
+        const uint32_t f = fl[i];
+        const uint32_t cls = f & CRAG_FLAG_CLASS_MASK;
+        double boost = cls == 1u ? 0.1 : (cls == 2u ? 1.2 : 1.0);
+        if (f & CRAG_FLAG_SYMBOL) boost = __dmul_rn(boost, symbol_boost);
+        const double s = __dmul_rn(base, boost);
+        score[j] = s;
+        keep[j] = s > 0.01;
+    }
+    __syncthreads();
+    // R5: stable descending sort + truncate, hybrid_search.py:124-125
+    for (int j = tid; j < nv; j += blockDim.x) {
+        if (!keep[j]) continue;
+        const double s = score[j];
+        int rank = 0;
+        for (int t = 0; t < nv; ++t) rank += keep[t] && (score[t] > s || (score[t] == s && t < j));
+        atomicAdd(&n_keep, 1);
+        if (rank < top_k) {
+            const int i = sel[j];
+            out_ids[(long long)q * top_k + rank] = ids[i];
+            out_scores[(long long)q * top_k + rank] = s;
+            out_dist[(long long)q * top_k + rank] = crag_fkey_inv(fk[i]);
+        }
+    }
+    __syncthreads();
+    const int nk = n_keep < top_k ? n_keep : top_k;
+    for (int j = nk + tid; j < top_k; j += blockDim.x) {
+        out_ids[(long long)q * top_k + j] = -1;
+        out_scores[(long long)q * top_k + j] = 0.0;
+        out_dist[(long long)q * top_k + j] = __builtin_inff();
+    }
+    if (tid == 0) out_counts[q] = nk;
+}
+
+// ----------------------------------------------------------------------------------------
+// exact fallback: canonical float32 distance of EVERY row (one thread per row), as 64-bit keys
+__global__ __launch_bounds__(256) void k_exact_keys(const void* __restrict__ rows, long long n,
+                                                    const void* __restrict__ query, int dtype, int dim, int dim_pad,
+                                                    int metric, unsigned long long* __restrict__ keys) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long off = r * dim_pad;
+    for (int d0 = 0; d0 < dim; d0 += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = d0 + j;
+            if (d < dim) {
+                const double a = load_elem_f64(query, dtype, d);
+                const double b = load_elem_f64(rows, dtype, off + d);
+                double p;
+                if (metric == CRAG_L2) {
+                    const double t = __dsub_rn(a, b);
+                    p = __dmul_rn(t, t);
+                } else {
+                    p = __dmul_rn(a, b);
+                }
+                acc[j] = __dadd_rn(acc[j], p);
+            }
+        }
+    }
+    double s = __dadd_rn(__dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3])),
+                         __dadd_rn(__dadd_rn(acc[4], acc[5]), __dadd_rn(acc[6], acc[7])));
+    if (metric == CRAG_IP) s = __dsub_rn(1.0, s);
+    keys[r] = ((unsigned long long)crag_fkey((float)s) << 32) | (unsigned long long)(uint32_t)r;
+}
+
+__global__ __launch_bounds__(256) void k_hist64(const unsigned long long* __restrict__ keys, long long n,
+                                                unsigned long long prefix, unsigned long long mask, int shift,
+                                                unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        if ((k & mask) == prefix) atomicAdd(&h[(unsigned int)(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_gather_le(const unsigned long long* __restrict__ keys, long long n,
+                                                   unsigned long long thr, unsigned long long* __restrict__ out,
+                                                   unsigned int* __restrict__ out_cnt, unsigned int cap) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        if (k <= thr) {
+            const unsigned int pos = atomicAdd(out_cnt, 1u);
+            if (pos < cap) out[pos] = k;
+        }
+    }
+}
+
+}  // namespace
+
+int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n, float* xnorm, float* max_out,
+                          hipStream_t s) {
+    if (n <= 0) return 0;
+    const int chunks = dim_pad * (dtype == CRAG_F32 ? 4 : 2) / 16;
+    long long blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)rows, dtype, chunks, n,
+                       xnorm, (unsigned int*)max_out);
+    return (int)hipGetLastError();
+}
+
+int crag_launch_tau_select(const uint32_t* sample, long long sample_stride, const QueryDesc* qd, int B, int M,
+                           float* tau, hipStream_t s) {
+    hipLaunchKernelGGL(k_tau_select, dim3(B), dim3(1024), 0, s, sample, sample_stride, qd, M, tau);
+    return (int)hipGetLastError();
+}
+
+int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s) {
+    const size_t lds = sizeof(unsigned long long) * (CRAG_CAND_CAP + CRAG_MAX_M) + sizeof(double) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(a.B), dim3(1024), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int crag_launch_merge_rerank(const CragEntry* entries, int G, int B, int kc, int top_k, double symbol_boost,
+                             long long* out_ids, double* out_scores, float* out_dist, int* out_counts,
+                             hipStream_t s) {
+    const int n = G * kc;
+    const size_t lds = (size_t)n * (8 + 4 + 4) + (size_t)kc * (8 + 4 + 4);
+    if (lds > 60 * 1024) return -2;
+    hipLaunchKernelGGL(k_merge_rerank, dim3(B), dim3(256), lds, s, entries, G, B, kc, top_k, symbol_boost, out_ids,
+                       out_scores, out_dist, out_counts);
+    return (int)hipGetLastError();
+}
+
+int crag_launch_exact_keys(const QueryDesc* qd_host, const void* query, int dtype, int dim, int dim_pad, int metric,
+                           unsigned long long* keys, hipStream_t s) {
+    const long long n = qd_host->n_rows;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_exact_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qd_host->rows, n, query,
+                       dtype, dim, dim_pad, metric, keys);
+    return (int)hipGetLastError();
+}
+
+int crag_launch_hist64(const unsigned long long* keys, long long n, unsigned long long prefix,
+                       unsigned long long mask, int shift, unsigned int* hist256, hipStream_t s) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_hist64, dim3((unsigned)blocks), dim3(256), 0, s, keys, n, prefix, mask, shift, hist256);
+    return (int)hipGetLastError();
+}
+
+int crag_launch_gather_le(const unsigned long long* keys, long long n, unsigned long long thr,
+                          unsigned long long* out, unsigned int* out_cnt, unsigned int cap, hipStream_t s) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_gather_le, dim3((unsigned)blocks), dim3(256), 0, s, keys, n, thr, out, out_cnt, cap);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,401 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/coderag_hip.h), against the
+CPU oracle on the same seeded inputs.  Bar: ids, float32 distances and float64 scores are
+BIT-EXACT (integer/index work and canonical fp64 arithmetic), counts identical.
+
+Run on the GPU box:  python -u -m pytest tests -m gpu -x -v --timeout 120 --timeout-method thread
+"""
+import glob
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import coderag_hip as ch
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+ENTRY = np.dtype([("dist", "<f4"), ("flags", "<u4"), ("id", "<i8")])
+
+
+# ---------------------------------------------------------------------------------------------
+def names_for_match(match: np.ndarray):
+    """Realise an arbitrary bool matrix match[nq, n] through real names and query texts: row i is
+    named after its match pattern, query b's text contains exactly the names with bit b set."""
+    nq, n = match.shape
+    assert nq <= 6
+    pat = np.zeros(n, np.int64)
+    for b in range(nq):
+        pat |= match[b].astype(np.int64) << b
+    names = ["" if p == 0 else f"Sym{int(p):02d}q" for p in pat]
+    texts = []
+    for b in range(nq):
+        used = sorted({names[i].lower() for i in range(n) if (pat[i] >> b) & 1})
+        texts.append("find " + " and ".join(used) + " please")
+    return names, texts
+
+
+def to_f32(rows):
+    return O.bf16_bits_to_f32(rows) if rows.dtype == np.uint16 else rows
+
+
+def make_collection(rows, dtype, metric="l2", names=None, classes=None, id_base=0):
+    col = ch.GpuCollection(rows.shape[1], dtype, metric)
+    kw = {}
+    if names is not None:
+        kw["names"] = names
+    if classes is not None:
+        kw["path_class"] = np.ascontiguousarray(classes, np.uint8)
+    col.add(rows, **kw)
+    if id_base:
+        col.set_id_base(id_base)
+    col.finalize()
+    return col
+
+
+def check_against_oracle(coracle, col, rows, queries, classes, match, top_k, sb, metric, texts, id_base=0):
+    ids, sc, di, cn = col.search(to_f32(queries), top_k, sb, query_texts=texts)
+    want = coracle.search_numeric(rows, queries, classes, match, top_k, sb, metric, id_base)
+    for b, (wi, ws, wd) in enumerate(want):
+        n = len(wi)
+        assert int(cn[b]) == n, (b, int(cn[b]), n)
+        assert np.array_equal(ids[b, :n], wi), (b, ids[b, :n], wi)
+        assert np.array_equal(di[b, :n].view(np.uint32), wd.view(np.uint32)), b
+        assert np.array_equal(sc[b, :n], ws), b
+        assert np.all(ids[b, n:] == -1)
+
+
+def synth_case(n, d, dtype, nq, seed=1234):
+    rows = O.synth_unit_rows(n, d, seed, dtype)
+    queries = O.synth_unit_rows(nq, d, seed + 1, dtype)
+    rng = np.random.default_rng(seed + 2)
+    classes = rng.choice(np.array([0, 1, 2], np.uint8), size=n, p=[0.70, 0.05, 0.25]).astype(np.uint8)
+    return rows, queries, classes, rng
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixtures(path):
+    g = np.load(path, allow_pickle=False)
+    rows, queries, match = g["rows"], g["queries"], g["match"]
+    top_k, sb, metric, dtype = int(g["top_k"]), float(g["symbol_boost"]), str(g["metric"]), str(g["dtype"])
+    names, texts = names_for_match(match)
+    col = make_collection(rows, dtype, metric, names, g["classes"])
+    ids, sc, di, cn = col.search(to_f32(queries), top_k, sb, query_texts=texts)
+    assert np.array_equal(cn, g["counts"])
+    for b in range(len(cn)):
+        n = int(cn[b])
+        assert np.array_equal(ids[b, :n], g["ids"][b, :n])
+        assert np.array_equal(sc[b, :n], g["scores"][b, :n])
+        assert np.array_equal(di[b, :n].view(np.uint32), g["dists"][b, :n].view(np.uint32))
+    assert col.stats()["fallback"] == 0
+
+
+@pytest.mark.parametrize("dtype,d,n,nq,top_k,metric", [
+    ("f32", 384, 20000, 1, 10, "l2"),       # C2 shape, GEMV NQ=1
+    ("f32", 384, 20000, 3, 10, "l2"),       # NQ=4 template, 3 real queries
+    ("f32", 384, 5000, 8, 8, "ip"),         # NQ=8
+    ("bf16", 768, 30000, 1, 10, "l2"),      # C3/C4 corpus, batch 1
+    ("bf16", 768, 30000, 5, 100, "l2"),     # top-100 -> 200 candidates, M=250
+    ("bf16", 1024, 9000, 2, 8, "l2"),       # C5 shape
+    ("bf16", 384, 7000, 4, 10, "ip"),
+    ("f32", 768, 3000, 2, 10, "l2"),        # C = 192
+    ("f32", 1024, 3000, 1, 5, "l2"),        # C = 256
+    ("bf16", 512, 4000, 6, 10, "l2"),       # C = 64
+    ("bf16", 256, 4000, 1, 10, "l2"),       # C = 32
+    ("f32", 100, 3000, 2, 10, "l2"),        # padded rows (400 B -> 512 B)
+    ("f32", 7, 500, 1, 3, "l2"),            # tiny dim
+    ("bf16", 1000, 2500, 3, 10, "l2"),      # padded bf16 rows
+    ("f32", 384, 20000, 20, 10, "l2"),      # f32, B > 8: several GEMV groups
+])
+def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
+    rows, queries, classes, rng = synth_case(n, d, dtype, nq)
+    m = min(nq, 6)
+    match = np.zeros((nq, n), np.uint8)
+    match[:m] = rng.random((m, n)) < 0.08
+    names, texts = names_for_match(match[:m])
+    texts = texts + ["no symbols here"] * (nq - m)
+    col = make_collection(rows, dtype, metric, names, classes)
+    col.set_path("gemv")
+    check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
+    assert col.stats()["gemv_batches"] >= 1
+
+
+@pytest.mark.parametrize("d,n,nq,top_k,metric", [
+    (768, 30000, 16, 10, "l2"),
+    (768, 30011, 130, 10, "l2"),            # ragged rows and queries (two query tiles)
+    (768, 9000, 256, 100, "l2"),            # C3-like: top-100
+    (1024, 5000, 33, 8, "l2"),
+    (384, 8000, 64, 10, "ip"),
+    (256, 300, 17, 10, "l2"),               # fewer rows than one sample tile
+])
+def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
+    rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)
+    match = np.zeros((nq, n), np.uint8)
+    match[:4] = rng.random((4, n)) < 0.08
+    names, texts = names_for_match(match[:4])
+    texts = texts + ["plain query"] * (nq - 4)
+    col = make_collection(rows, "bf16", metric, names, classes)
+    col.set_path("mfma")
+    check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
+    st = col.stats()
+    assert st["mfma_batches"] >= 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 19, 20, 21, 63, 64, 65, 127, 129, 4095, 4097])
+def test_small_and_ragged_collections(coracle, n):
+    rows, queries, classes, _ = synth_case(n, 384, "f32", 2, seed=5)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+
+
+def test_empty_collection_returns_nothing():
+    col = ch.GpuCollection(64, "f32")
+    col.finalize()
+    ids, sc, di, cn = col.search(np.ones((2, 64), np.float32), 5)
+    assert list(cn) == [0, 0] and np.all(ids == -1)
+
+
+def test_symbol_boost_threshold_and_penalties(coracle):
+    """R4: with symbol_boost < 0.5 the > 0.01 filter bites; penalised rows are overtaken."""
+    rows, queries, classes, rng = synth_case(6000, 384, "f32", 3, seed=21)
+    match = (rng.random((3, 6000)) < 0.5).astype(np.uint8)
+    names, texts = names_for_match(match)
+    col = make_collection(rows, "f32", "l2", names, classes)
+    for sb in (0.004, 0.02, 1.0, 2.5):
+        check_against_oracle(coracle, col, rows, queries, classes, match, 10, sb, "l2", texts)
+
+
+def test_exact_ties_and_duplicates_use_row_id_order(coracle):
+    base = O.synth_unit_rows(7, 384, 3, "f32")
+    rows = np.tile(base, (300, 1))                       # every vector 300 times: massive exact ties
+    queries = O.synth_unit_rows(2, 384, 4, "f32")
+    classes = np.zeros(len(rows), np.uint8)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+
+
+def test_near_ties_force_the_exact_fallback(coracle):
+    """Rows that differ from each other by one float32 ulp in one coordinate: the approximate scan
+    cannot separate them, the certificate must fail and the exact fallback must still agree."""
+    rng = np.random.default_rng(9)
+    n, d = 5000, 384
+    q = O.synth_unit_rows(1, d, 10, "f32")
+    rows = np.tile(q, (n, 1)).astype(np.float32)
+    col_idx = rng.integers(0, d, n)
+    for i in range(n):
+        v = rows[i, col_idx[i]]
+        rows[i, col_idx[i]] = np.nextafter(v, np.float32(np.inf) if i % 2 else np.float32(-np.inf))
+    rows[::7] *= np.float32(1.0000001)
+    classes = np.zeros(n, np.uint8)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, q, classes, None, 10, 2.0, "l2", None)
+    assert col.stats()["fallback"] >= 1
+
+
+def test_stage1_entries_equal_oracle_candidates(coracle):
+    import torch
+    rows, queries, classes, rng = synth_case(12000, 768, "bf16", 4, seed=31)
+    match = (rng.random((4, 12000)) < 0.1).astype(np.uint8)
+    names, texts = names_for_match(match)
+    col = make_collection(rows, "bf16", "l2", names, classes, id_base=1000)
+    top_k, kc = 10, 20
+    q = torch.from_numpy(queries.view(np.int16)).cuda().view(torch.bfloat16)
+    hashes = [col.symbol_hashes(t) for t in texts]
+    off = np.zeros(5, np.int32)
+    np.cumsum([len(h) for h in hashes], out=off[1:])
+    qh = torch.from_numpy(np.concatenate(hashes).view(np.int64)).cuda()
+    qo = torch.from_numpy(off).cuda()
+    ent = torch.zeros((4, kc, 16), dtype=torch.uint8, device="cuda")
+    col.search_local_device(q, top_k, ent, qh, qo)
+    e = ent.cpu().numpy().reshape(4, kc * 16).view(ENTRY)
+    ids, dist, _ = coracle.knn(rows, queries, kc, "l2", id_base=1000)
+    assert np.array_equal(e["id"], ids)
+    assert np.array_equal(e["dist"].view(np.uint32), dist.view(np.uint32))
+    for b in range(4):
+        pos = ids[b] - 1000
+        assert np.array_equal(e["flags"][b] & 3, classes[pos])
+        assert np.array_equal((e["flags"][b] >> 2) & 1, match[b][pos])
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_sharded_merge_equals_single_collection(coracle, n_shards):
+    """Multi-GPU path on one GPU: G shard collections with global id bases, stage 1 on each, the
+    gathered [G, B, kc, 16] entries merged by the stage-2 kernel."""
+    import torch
+    from coderag_hip.dist import shard_range
+    n, d, nq, top_k = 20001, 768, 5, 10
+    rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=41)
+    match = (rng.random((nq, n)) < 0.1).astype(np.uint8)
+    names, texts = names_for_match(match)
+    q = torch.from_numpy(queries.view(np.int16)).cuda().view(torch.bfloat16)
+    ents = torch.zeros((n_shards, nq, 2 * top_k, 16), dtype=torch.uint8, device="cuda")
+    cols = []
+    for r in range(n_shards):
+        lo, hi = shard_range(n, r, n_shards)
+        c = make_collection(rows[lo:hi], "bf16", "l2", names[lo:hi], classes[lo:hi], id_base=lo)
+        cols.append(c)
+        hashes = [c.symbol_hashes(t) for t in texts]
+        off = np.zeros(nq + 1, np.int32)
+        np.cumsum([len(h) for h in hashes], out=off[1:])
+        cat = np.concatenate(hashes) if sum(map(len, hashes)) else np.zeros(1, np.uint64)
+        c.search_local_device(q, top_k, ents[r], torch.from_numpy(cat.view(np.int64)).cuda(),
+                              torch.from_numpy(off).cuda())
+    ids, sc, di, cn = ch.merge_rerank_device(0, ents, n_shards, nq, top_k, 2.0)
+    torch.cuda.synchronize()
+    want = coracle.search_numeric(rows, queries, classes, match, top_k, 2.0, "l2")
+    for b, (wi, ws, wd) in enumerate(want):
+        k = len(wi)
+        assert int(cn[b]) == k
+        assert np.array_equal(ids[b, :k].cpu().numpy(), wi)
+        assert np.array_equal(sc[b, :k].cpu().numpy(), ws)
+        assert np.array_equal(di[b, :k].cpu().numpy().view(np.uint32), wd.view(np.uint32))
+
+
+def test_workspace_isolated_collections_queried_together(coracle):
+    """C5 in miniature: every query addresses its own collection; a query only sees its own rows."""
+    d, top_k = 1024, 8
+    sizes = [3000, 1, 700, 4500, 64, 2500, 2500]
+    cols, data, qs = [], [], []
+    for i, n in enumerate(sizes):
+        rows, queries, classes, _ = synth_case(n, d, "bf16", 1, seed=100 + i)
+        cols.append(make_collection(rows, "bf16", "l2", None, classes))
+        data.append((rows, classes))
+        qs.append(queries[0])
+    order = [0, 0, 1, 2, 3, 3, 3, 4, 5, 6, 0]
+    q = np.stack([qs[i] for i in order])
+    ids, sc, di, cn = ch.search_multi([cols[i] for i in order], to_f32(q), top_k, 2.0)
+    for b, i in enumerate(order):
+        rows, classes = data[i]
+        (wi, ws, wd), = coracle.search_numeric(rows, q[b:b + 1], classes, None, top_k, 2.0, "l2")
+        k = len(wi)
+        assert int(cn[b]) == k and np.array_equal(ids[b, :k], wi) and np.array_equal(sc[b, :k], ws)
+
+
+def test_concurrent_searches_on_one_handle(coracle):
+    rows, queries, classes, _ = synth_case(20000, 384, "f32", 8, seed=51)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    want = coracle.search_numeric(rows, queries, classes, None, 10, 2.0, "l2")
+    errs = []
+
+    def work(b):
+        try:
+            for _ in range(5):
+                ids, sc, di, cn = col.search(queries[b:b + 1], 10, 2.0)
+                assert np.array_equal(ids[0, :int(cn[0])], want[b][0]) and np.array_equal(sc[0, :int(cn[0])], want[b][1])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(b,)) for b in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+
+
+def test_c2_full_size_batch1(coracle):
+    """configs[1]: 1M x 384 fp32, batch-1, top-10 -- full size, against the C oracle."""
+    rows = O.synth_unit_rows(1_000_000, 384, 1234, "f32")
+    queries = O.synth_unit_rows(2, 384, 1235, "f32")
+    classes = np.zeros(len(rows), np.uint8)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+    assert col.stats()["fallback"] == 0
+
+
+def test_full_size_10m_bf16_properties():
+    """BASELINE.json's metric corpus (10M x 768 bf16) is too big for the CPU oracle in a test, so
+    check size-independent properties: planted exact copies of the query come back first with
+    distance 0 in ascending id order, distances ascend, ids are distinct, and the reported
+    distances agree with an fp64 recomputation of the returned rows."""
+    import torch
+    n, d, nq, top_k = 10_000_000, 768, 32, 10
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    rows = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    for lo in range(0, n, 1_000_000):
+        x = torch.randn((1_000_000, d), generator=g, device="cuda", dtype=torch.float32)
+        rows[lo:lo + 1_000_000] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    q = torch.randn((nq, d), generator=g, device="cuda", dtype=torch.float32)
+    q = (q / q.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    planted = [9_999_999, 5, 7_654_321]
+    for p in planted:
+        rows[p] = q[0]
+    col = ch.GpuCollection(d, "bf16", "l2")
+    col.attach_device(rows)
+    col.finalize()
+    for path in ("mfma", "gemv"):
+        col.set_path(path)
+        qq = q if path == "mfma" else q[:4].contiguous()
+        ids, sc, di, cn = [t.cpu().numpy() for t in col.search_device(qq, top_k, 2.0)]
+        assert list(ids[0, :3]) == sorted(planted) and np.all(di[0, :3] == 0.0) and np.all(sc[0, :3] == 1.0)
+        for b in range(len(qq)):
+            assert int(cn[b]) == top_k and len(set(ids[b])) == top_k
+            assert np.all(np.diff(di[b]) >= 0)
+            r = rows[torch.from_numpy(ids[b]).cuda()].double()
+            ref = ((qq[b].double()[None, :] - r) ** 2).sum(1).cpu().numpy()
+            assert np.allclose(di[b], ref, rtol=1e-6, atol=1e-7)
+            assert np.allclose(sc[b], 1.0 / (1.0 + di[b].astype(np.float64)), rtol=0, atol=0)
+        # the 10th distance must not exceed the 10th smallest of an independent fp32 brute force
+        approx = torch.cdist(qq[:2].float(), rows[:2_000_000].float()).pow(2).topk(top_k, largest=False).values
+        assert np.all(di[:2, -1] <= approx[:, -1].cpu().numpy() + 1e-5)
+    assert col.stats()["fallback"] == 0
+
+
+# ---------------------------------------------------------------------------------------------
+def _chunks(n, rng):
+    words = ["chunk", "asciiToArray", "stringSize", "hasUnicode", "Parser", "baseFlatten", "debounce", "map", "a",
+             "größe", "isArrayLike", "castPath", ""]
+    dirs = ["lodash/src/", "src/", "pkg/test/", "lib/", "a/lib/", "types/", "x/__tests__/", "docs/spec/", ""]
+    metas, ids, docs = [], [], []
+    for i in range(n):
+        w = words[int(rng.integers(0, len(words)))]
+        p = dirs[int(rng.integers(0, len(dirs)))] + (f"f{i % 17}.d.ts" if i % 11 == 0 else f"f{i % 17}.js")
+        m = {"name": w, "path": p, "kind": "Function" if i % 2 else "Class", "start_line": i, "end_line": i + 3}
+        metas.append(None if i % 97 == 0 else m)
+        ids.append(f"{i:012x}")
+        docs.append(f"function {w}() {{\n  return {i};\n}}")
+    return ids, metas, docs
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hybrid_searcher_end_to_end(tmp_path, dtype):
+    rng = np.random.default_rng(61)
+    n = 3000
+    ids, metas, docs = _chunks(n, rng)
+    emb = ch.HashingEmbedder()
+    vecs = emb(docs)
+    hs = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=emb, dtype=dtype)
+    col = hs.create_collection("code_chunks__ws1", 384)
+    for lo in range(0, n, 100):                                    # batches of 100, embed_ingest.py:90-105
+        col.add(ids[lo:lo + 100], vecs[lo:lo + 100], metas[lo:lo + 100], docs[lo:lo + 100])
+    col.gpu.finalize()
+    rows = vecs if dtype == "f32" else O.f32_to_bf16_bits(vecs)
+    queries = ["Find the implementation of lodash chunk", "What does asciiToArray do?",
+               "How to count unicode symbols length in lodash? stringSize hasUnicode", "GRÖSSE größe Parser", "zzz"]
+    for q in queries:
+        qv = emb([q])[0]
+        qv = qv if dtype == "f32" else O.f32_to_bf16_bits(qv)
+        for top_k, sb, inc in ((8, 2.0, False), (6, 2.5, True), (3, 0.3, False)):
+            got = hs.search(q, top_k=top_k, symbol_boost=sb, include_documents=inc, collection_name="code_chunks__ws1")
+            want = O.oracle_search(qv, q, rows, ids, metas, docs, top_k, sb, inc)
+            assert got == want
+    assert hs.search("x", collection_name="code_chunks__nope") == []
+    # /search response shape + post filters (api/main.py:151-216)
+    r = ch.search_route(hs, queries[0], top_k=8, x_workspace_id="ws1", path_prefix="lodash/")
+    w = O.search_response(queries[0], O.oracle_search(emb([queries[0]])[0] if dtype == "f32" else
+                                                      O.f32_to_bf16_bits(emb([queries[0]])[0]),
+                                                      queries[0], rows, ids, metas, docs, 8, 2.0, False),
+                          path_prefix="lodash/")
+    assert r == w
+    # search_by_symbol: exact branch and fallback branch (hybrid_search.py:128-146)
+    got = hs.search_by_symbol("Parser", top_k=4, collection_name="code_chunks__ws1")
+    assert got == O.search_by_symbol("Parser", ids, metas, docs, 4)
+    fb = hs.search_by_symbol("nonexistentSymbol", top_k=4, collection_name="code_chunks__ws1")
+    assert fb == hs.search("nonexistentSymbol", top_k=4, include_documents=True, collection_name="code_chunks__ws1")
+    # persistence round trip (store.py stands where data/chroma_db stands)
+    from coderag_hip import store
+    store.save_collection(str(tmp_path), col)
+    hs2 = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=emb, dtype=dtype)
+    assert hs2.search(queries[0], 8, collection_name="code_chunks__ws1") == hs.search(queries[0], 8, collection_name="code_chunks__ws1")
+    batch = hs.search_batch(queries, top_k=8, collection_name="code_chunks__ws1")
+    assert batch == [hs.search(q, 8, collection_name="code_chunks__ws1") for q in queries]

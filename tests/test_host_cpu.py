@@ -1,0 +1,112 @@
+"""CPU tests of the host logic and the C-ABI boundary: the library loads and exports every symbol
+include/coderag_hip.h declares (no compute call: there is no GPU here), hashing / path
+classification / naming agree with the oracle, and the product refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import coderag_hip as ch
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "coderag_hip.h")).read()
+    declared = set(re.findall(r"\b(crag_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(ch.SYMBOLS), declared ^ set(ch.SYMBOLS)
+    lib = ch.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.crag_version() >= 100
+
+
+def _fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for c in b:
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h or 1
+
+
+def test_name_hashes_are_fnv1a_of_lowered_utf8():
+    names = ["chunk", "Chunk", "", "asciiToArray", "größe", "名前", "a"]
+    h, l = ch.hash_names(names)
+    for n, hv, lv in zip(names, h, l):
+        b = n.lower().encode("utf-8")
+        assert int(lv) == len(b)
+        assert int(hv) == (0 if not b else _fnv1a(b))
+    assert h[0] == h[1]
+
+
+@pytest.mark.parametrize("path", ["pkg/src/a.js", "src/a.js", "a/test/b.js", "a/tests/b.js", "a/spec/b.js",
+                                  "a/__tests__/b.js", "types/x.d.ts", "a/test/src/b.js", "A/SRC/b.js", "x/lib/y", "",
+                                  None, 12])
+def test_classify_path_matches_oracle(path):
+    assert ch.classify_path(path) == O.path_class(path)
+
+
+def test_bf16_cast_matches_oracle():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(5000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.00390625, 1.01171875, np.inf, -np.inf, 1e-40], np.float32)])
+    assert np.array_equal(ch.f32_to_bf16_bits(x), O.f32_to_bf16_bits(x))
+
+
+@pytest.mark.parametrize("ws", [None, "", "default", " default ", "abc", "a b/c", "x" * 100, "!!!", "ü-1"])
+def test_collection_name_matches_oracle(ws):
+    assert ch.get_collection_name(ws) == O.collection_name_for(ws)
+
+
+class _FakeSearcher:
+    def __init__(self, rows):
+        self.rows = rows
+        self.calls = []
+
+    def search(self, query, top_k=10, symbol_boost=2.0, include_documents=False, collection_name="code_chunks"):
+        self.calls.append((query, top_k, symbol_boost, include_documents, collection_name))
+        return self.rows
+
+
+def test_search_route_matches_oracle_response():
+    rows = [{"id": "a", "score": 0.9, "metadata": {"name": "f", "kind": "Function", "path": "src/a.js",
+                                                   "start_line": 3, "end_line": None}, "text_preview": "p"},
+            {"id": "b", "score": 0.2, "metadata": {"path": "lib\\b.js"}, "text_preview": ""}]
+    fs = _FakeSearcher(rows)
+    for kw in ({}, {"path_prefix": "lib/"}, {"kind": "function"}, {"min_score": 0.5}):
+        assert ch.search_route(fs, "q", x_workspace_id="w 1", **kw) == O.search_response("q", rows, **kw)
+    assert fs.calls[0] == ("q", 10, 2.0, False, "code_chunks__w_1")
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    lib = ch.load()
+    if lib.crag_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ch.CragError):
+        ch.GpuCollection(16)
+    hs = ch.HybridSearcher(db_path="/nonexistent")
+    with pytest.raises(ch.CragError):
+        hs.create_collection("code_chunks", 16)
+    assert hs.search("anything") == []          # missing collection -> [] (hybrid_search.py:54-56)
+
+
+def test_shard_ranges_partition_rows():
+    from coderag_hip.dist import shard_range
+    for n in (0, 1, 7, 8, 100, 100_000_001):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_hashing_embedder_is_unit_norm_and_deterministic():
+    e = ch.HashingEmbedder()
+    a = e(["Find the implementation of lodash chunk", ""])
+    b = e(["Find the implementation of lodash chunk"])
+    assert a.shape == (2, 384) and a.dtype == np.float32
+    assert np.allclose(np.linalg.norm(a, axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(a[0], b[0])

@@ -26,7 +26,7 @@ SYMBOLS = [
     "crag_hash_name", "crag_hash_names", "crag_symbol_hashes",
     "crag_search", "crag_search_multi", "crag_search_device",
     "crag_search_local_device", "crag_merge_rerank_device",
-    "crag_stats", "crag_set_path", "crag_set_profiling", "crag_get_profile",
+    "crag_stats", "crag_set_path", "crag_set_profiling", "crag_get_profile", "crag_debug_dense_scores",
 ]
 
 _lib = None
@@ -74,6 +74,7 @@ def load() -> C.CDLL:
     lib.crag_set_path.argtypes = [vp, i32]
     lib.crag_set_profiling.argtypes = [vp, i32]
     lib.crag_get_profile.argtypes = [vp, vp, i32]
+    lib.crag_debug_dense_scores.argtypes = [vp, vp, i32, i32, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("crag_version", "crag_device_count"):

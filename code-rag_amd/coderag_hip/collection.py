@@ -257,6 +257,19 @@ class GpuCollection:
         keys = ["searches", "queries", "fallback", "uncertified", "overflow", "mfma_batches", "gemv_batches"]
         return dict(zip(keys, (int(x) for x in a)))
 
+    def debug_dense_scores(self, queries, path: str = "gemv"):
+        """Test hook: approximate scan scores of every row, CUDA float32 [B, rows]."""
+        import torch
+        if not self._finalized:
+            self.finalize()
+        self._check_tensor(queries)
+        out = torch.empty((queries.shape[0], len(self)), dtype=torch.float32, device=queries.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.crag_debug_dense_scores(self._h, queries.data_ptr(), queries.shape[0],
+                                                {"gemv": 1, "mfma": 2}[path], out.data_ptr(), st),
+              "crag_debug_dense_scores")
+        return out
+
     def set_profiling(self, on: bool):
         check(self._lib.crag_set_profiling(self._h, int(bool(on))))
 

@@ -856,6 +856,80 @@ int crag_stats(crag_index* h, int64_t* out7, int reset) {
     return 0;
 }
 
+int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int path, float* out_scores_dev,
+                            void* stream) {
+    if (!h || !queries_dev || !out_scores_dev || B <= 0) return fail(CRAG_E_INVALID, "crag_debug_dense_scores: bad arguments");
+    if (!h->finalized) return fail(CRAG_E_STATE, "collection not finalized");
+    HIPCHK(hipSetDevice(h->device));
+    WsGuard guard(h->device);
+    if (!guard.w) return fail(CRAG_E_HIP, "could not create a HIP stream");
+    Workspace* ws = guard.w;
+    hipStream_t st = (hipStream_t)stream;
+    const void* q = nullptr;
+    int rc;
+    if ((rc = stage_device_queries(h, queries_dev, B, ws, st, &q))) return rc;
+    const long long n = h->n_rows;
+    const long long stride = n;
+    if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)std::max<long long>(stride, 1)))) return rc;
+    if (path == 2) {
+        if (h->dtype != CRAG_BF16) return fail(CRAG_E_INVALID, "mfma path needs a bf16 collection");
+        MfmaArgs a;
+        memset(&a, 0, sizeof(a));
+        a.rows = h->rows;
+        a.xnorm = h->xnorm;
+        a.n_rows = n;
+        a.row_begin = 0;
+        a.row_end = n;
+        a.queries = q;
+        a.n_queries = B;
+        a.dim_pad = h->dim_pad;
+        a.metric = h->metric;
+        a.sample = (uint32_t*)ws->sample.p;
+        a.sample_stride = stride;
+        if (crag_launch_scan_mfma(a, 0, st)) return fail(CRAG_E_HIP, "mfma launch failed");
+    } else {
+        std::vector<GroupDesc> gd;
+        int blk = 0;
+        for (int b = 0; b < B; b += CRAG_MAX_GROUP_Q) {
+            GroupDesc g;
+            memset(&g, 0, sizeof(g));
+            g.rows = h->rows;
+            g.xnorm = h->xnorm;
+            g.n_rows = n;
+            g.n_sample = n;
+            g.q_first = b;
+            g.nq = std::min(CRAG_MAX_GROUP_Q, B - b);
+            g.blk_first[0] = blk;
+            g.n_blk[0] = (int)std::min<long long>(512, (n + 255) / 256);
+            blk += g.n_blk[0];
+            gd.push_back(g);
+        }
+        const int nqt = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
+        if ((rc = ws->desc.ensure(sizeof(GroupDesc) * gd.size()))) return rc;
+        HIPCHK(hipMemcpyAsync(ws->desc.p, gd.data(), sizeof(GroupDesc) * gd.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ScanArgs a;
+        memset(&a, 0, sizeof(a));
+        a.groups = (const GroupDesc*)ws->desc.p;
+        a.n_groups = (int)gd.size();
+        a.queries = q;
+        a.dtype = h->dtype;
+        a.chunks = h->chunks;
+        a.metric = h->metric;
+        a.sample = (uint32_t*)ws->sample.p;
+        a.sample_stride = stride;
+        if (crag_launch_scan_gemv(a, 0, nqt, blk, st)) return fail(CRAG_E_HIP, "gemv launch failed");
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    // keys -> floats on the host side of the boundary is the caller's job; here we decode on the host
+    std::vector<uint32_t> keys((size_t)B * (size_t)n);
+    HIPCHK(hipMemcpy(keys.data(), ws->sample.p, keys.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> sc(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) sc[i] = crag_fkey_inv(keys[i]);
+    HIPCHK(hipMemcpy(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int crag_set_profiling(crag_index* h, int on) {
     if (!h) return fail(CRAG_E_INVALID, "crag_set_profiling: null handle");
     h->profiling = on ? 1 : 0;

@@ -25,6 +25,17 @@ __device__ __forceinline__ float dpp_mov(float v) {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
+// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.   v_permlane16_swap: odd 16-lane rows
+// of a <-> even rows of b.  Inline asm, because hipcc (ROCm 7.2) folds the builtin's second
+// result onto the first (__builtin_amdgcn_permlane32_swap(...)[1] reads vdst, seen on hardware).
+// The two leading wait states cover the VALU-write -> permlane-read hazard inside the string.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 template <int DT>
 __device__ __forceinline__ float dot_chunk(uint4 x, uint4 q, float acc) {
     if constexpr (DT == CRAG_BF16) {
@@ -46,14 +57,16 @@ __device__ __forceinline__ float butterfly64(float (&v)[64], int lane) {
     float w[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {  // xor 32: lanes <32 keep value i, lanes >=32 keep value i+32
-        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[i]), __builtin_bit_cast(unsigned, v[i + 32]), false, false);
-        w[i] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+        float a = v[i], b = v[i + 32];
+        permlane32_swap(a, b);
+        w[i] = a + b;
     }
     float x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {  // xor 16: lane row rho=(l>>4) keeps value i + 16*rho
-        auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, w[i]), __builtin_bit_cast(unsigned, w[i + 16]), false, false);
-        x[i] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+        float a = w[i], b = w[i + 16];
+        permlane16_swap(a, b);
+        x[i] = a + b;
     }
     const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
     float y[8];

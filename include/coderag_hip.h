@@ -172,6 +172,13 @@ int crag_set_path(crag_index* h, int path);
  * kernel), [2] searches timed.
  */
 int crag_set_profiling(crag_index* h, int on);
+/*
+ * Test hook: the scan kernels' approximate score (|x|^2 - 2<q,x> for l2, -<q,x> for ip) of EVERY
+ * row, out_scores_dev [B][rows] float32, through path 1 (gemv) or 2 (mfma).  Tests use it to
+ * check the float32 error bound the exactness certificate relies on.  Slow; not a product path.
+ */
+int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int path, float* out_scores_dev,
+                            void* stream);
 int crag_get_profile(crag_index* h, double* out3, int reset);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_select.hip", "crag_capi.hip"]
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_select.hip", "crag_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -153,6 +153,7 @@ struct crag_index {
     std::vector<uint8_t> len_present;  // index = byte length
     int max_name_len = 0;
     int force_path = 0;
+    int n_cus = 256;
     int profiling = 0;
     std::mutex prof_mu;
     double prof[4] = {0, 0, 0, 0};  // sample-scan ms, filter-scan ms, searches timed, unused
@@ -223,13 +224,17 @@ int add_common(crag_index* h, const void* rows, int64_t n, const uint64_t* name_
     return 0;
 }
 
-long long n_sample_for(long long N, int M) {
-    if (N <= 0) return 0;
-    long long t = (long long)((double)N * (double)M / 2048.0);
-    t = std::min(t, N / 16);
-    t = std::max<long long>(t, 4096);
-    t = (t + 127) / 128 * 128;
-    return std::min(t, N);
+// Threshold cascade (DESIGN.md "Selection"): level 0 = dense scores of the first n0 rows, level 1 =
+// filtered scan of the first n1 rows with tau0, level 2 = filtered scan of all rows with tau1.
+// tau_l = M-th smallest score of level l's rows, so at least M rows pass every filter; expected
+// candidates per query: M*n1/n0 at level 1 and M*N/n1 at level 2, balanced by n1 = sqrt(n0*N).
+long long level0_rows(long long N, int M) { return std::min<long long>(N, M <= 64 ? 4096 : 16384); }
+long long level1_rows(long long N, long long n0, int M) {
+    if (N <= n0) return n0;
+    if ((double)M * (double)N / (double)n0 <= CRAG_CAND_CAP / 8) return n0;  // level 2 alone is cheap enough
+    long long n1 = (long long)std::sqrt((double)n0 * (double)N);
+    n1 = (n1 + 127) / 128 * 128;
+    return std::max(n0, std::min(n1, N));
 }
 
 struct Plan {
@@ -237,8 +242,9 @@ struct Plan {
     bool mfma = false;
     int nq_template = 1;
     int n_groups = 0;
-    int blocks[2] = {0, 0};
+    int blocks[3] = {0, 0, 0};
     long long sample_stride = 0;
+    bool need_mid = false;
 };
 
 // one batch on one device: queries already on the device in index dtype, row stride dim_pad
@@ -254,7 +260,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if (P.M > CRAG_MAX_M) P.M = CRAG_MAX_M;
 
     const int path = h0->force_path;
-    P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 16));
+    P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 9));
 
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
@@ -267,11 +273,13 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         d.name_hash = (const unsigned long long*)h->name_hash;
         d.path_class = h->path_class;
         d.n_rows = h->n_rows;
-        d.n_sample = n_sample_for(h->n_rows, P.M);
+        d.n_sample = level0_rows(h->n_rows, P.M);
+        d.n_mid = level1_rows(h->n_rows, d.n_sample, P.M);
         d.id_base = h->id_base;
         d.max_xnorm = h->max_xnorm;
         d.pad = 0;
         P.sample_stride = std::max<long long>(P.sample_stride, d.n_sample);
+        P.need_mid = P.need_mid || d.n_mid > d.n_sample;
     }
     P.sample_stride = (P.sample_stride + 63) / 64 * 64;
     if (!P.mfma) {
@@ -286,6 +294,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             g.xnorm = hs[b]->xnorm;
             g.n_rows = hs[b]->n_rows;
             g.n_sample = qd[(size_t)b].n_sample;
+            g.n_mid = qd[(size_t)b].n_mid;
             g.q_first = b;
             g.nq = e - b;
             max_nq = std::max(max_nq, g.nq);
@@ -294,26 +303,31 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         }
         P.nq_template = max_nq <= 1 ? 1 : (max_nq <= 2 ? 2 : (max_nq <= 4 ? 4 : 8));
         const int RT = 64 / P.nq_template;
-        const long long max_waves = 256LL * 12;
-        for (int mode = 0; mode < 2; ++mode) {
+        const long long max_waves = (long long)h0->n_cus * 12;
+        for (int pass = 0; pass < 3; ++pass) {
+            auto rows_of = [&](const GroupDesc& g) {
+                if (pass == 0) return g.n_sample;
+                if (pass == 1) return g.n_mid > g.n_sample ? g.n_mid : 0LL;  // level 1 only where it exists
+                return g.n_rows;
+            };
             long long total_st = 0;
-            for (auto& g : gd) total_st += ((mode ? g.n_rows : g.n_sample) + RT - 1) / RT;
+            for (auto& g : gd) total_st += (rows_of(g) + RT - 1) / RT;
             int blk = 0;
             for (auto& g : gd) {
-                const long long stg = ((mode ? g.n_rows : g.n_sample) + RT - 1) / RT;
-                g.blk_first[mode] = blk;
+                const long long stg = (rows_of(g) + RT - 1) / RT;
+                g.blk_first[pass] = blk;
                 if (stg == 0) {
-                    g.n_blk[mode] = 0;
+                    g.n_blk[pass] = 0;
                     continue;
                 }
                 long long share = std::max<long long>(4, max_waves * stg / std::max<long long>(total_st, 1));
                 long long waves = std::min(stg, share);
                 const long long T = (stg + waves - 1) / waves;
                 waves = (stg + T - 1) / T;
-                g.n_blk[mode] = (int)((waves + 3) / 4);
-                blk += g.n_blk[mode];
+                g.n_blk[pass] = (int)((waves + 3) / 4);
+                blk += g.n_blk[pass];
             }
-            P.blocks[mode] = blk;
+            P.blocks[pass] = blk;
         }
     }
     P.n_groups = (int)gd.size();
@@ -325,7 +339,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if ((rc = ws->desc.ensure(desc_bytes))) return rc;
     if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
     if ((rc = ws->cntst.ensure(sizeof(uint32_t) * 2 * (size_t)B))) return rc;
-    if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)P.sample_stride))) return rc;
+    const bool qreg = P.mfma && crag_qreg_supported(h0->dim_pad);
+    const long long bpad = ((long long)B + 15) / 16 * 16;
+    if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
     if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * CRAG_CAND_CAP))) return rc;
     memcpy(ws->pinned, qd.data(), sizeof(QueryDesc) * (size_t)B);
     if (!gd.empty()) memcpy((char*)ws->pinned + sizeof(QueryDesc) * (size_t)B, gd.data(), sizeof(GroupDesc) * gd.size());
@@ -334,60 +350,95 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     const GroupDesc* gd_dev = (const GroupDesc*)((char*)ws->desc.p + sizeof(QueryDesc) * (size_t)B);
     uint32_t* cnt = (uint32_t*)ws->cntst.p;
     uint32_t* status = cnt + B;
+    float* tau = (float*)ws->tau.p;
+    uint32_t* sample = (uint32_t*)ws->sample.p;
+    unsigned long long* cand = (unsigned long long*)ws->cand.p;
     HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)B, st));
 
     // ---- passes ----
     const bool prof = h0->profiling != 0;
     if (prof && (rc = ws->ensure_events())) return rc;
+    MfmaArgs ma;
+    ScanArgs ga;
     if (P.mfma) {
-        MfmaArgs a;
-        a.rows = h0->rows;
-        a.xnorm = h0->xnorm;
-        a.n_rows = h0->n_rows;
-        a.queries = q_dev;
-        a.n_queries = B;
-        a.dim_pad = h0->dim_pad;
-        a.metric = h0->metric;
-        a.tau = (const float*)ws->tau.p;
-        a.sample = (uint32_t*)ws->sample.p;
-        a.sample_stride = P.sample_stride;
-        a.cand = (unsigned long long*)ws->cand.p;
-        a.cnt = cnt;
-        a.row_begin = 0;
-        a.row_end = qd[0].n_sample;
-        if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
-        if ((rc = crag_launch_scan_mfma(a, 0, st))) return fail(CRAG_E_HIP, "mfma sample launch failed");
-        if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
-        if ((rc = crag_launch_tau_select((const uint32_t*)ws->sample.p, P.sample_stride, qd_dev, B, P.M, (float*)ws->tau.p, st)))
-            return fail(CRAG_E_HIP, "tau_select launch failed");
-        a.row_end = h0->n_rows;
-        if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
-        if ((rc = crag_launch_scan_mfma(a, 1, st))) return fail(CRAG_E_HIP, "mfma filter launch failed");
-        if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+        ma.rows = h0->rows;
+        ma.xnorm = h0->xnorm;
+        ma.n_rows = h0->n_rows;
+        ma.queries = q_dev;
+        ma.n_queries = B;
+        ma.dim_pad = h0->dim_pad;
+        ma.metric = h0->metric;
+        ma.tau = tau;
+        ma.sample = sample;
+        ma.sample_stride = qreg ? bpad : P.sample_stride;  // qreg: row-major sample [row][bpad]
+        ma.cand = cand;
+        ma.cnt = cnt;
+        ma.row_begin = 0;
         h0->stats[5]++;
     } else {
-        ScanArgs a;
-        a.groups = gd_dev;
-        a.n_groups = P.n_groups;
-        a.queries = q_dev;
-        a.dtype = h0->dtype;
-        a.chunks = h0->chunks;
-        a.metric = h0->metric;
-        a.tau = (const float*)ws->tau.p;
-        a.sample = (uint32_t*)ws->sample.p;
-        a.sample_stride = P.sample_stride;
-        a.cand = (unsigned long long*)ws->cand.p;
-        a.cnt = cnt;
-        if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
-        if ((rc = crag_launch_scan_gemv(a, 0, P.nq_template, P.blocks[0], st))) return fail(CRAG_E_HIP, "gemv sample launch failed");
-        if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
-        if ((rc = crag_launch_tau_select((const uint32_t*)ws->sample.p, P.sample_stride, qd_dev, B, P.M, (float*)ws->tau.p, st)))
-            return fail(CRAG_E_HIP, "tau_select launch failed");
-        if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
-        if ((rc = crag_launch_scan_gemv(a, 1, P.nq_template, P.blocks[1], st))) return fail(CRAG_E_HIP, "gemv filter launch failed");
-        if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+        ga.groups = gd_dev;
+        ga.n_groups = P.n_groups;
+        ga.queries = q_dev;
+        ga.dtype = h0->dtype;
+        ga.chunks = h0->chunks;
+        ga.metric = h0->metric;
+        ga.tau = tau;
+        ga.sample = sample;
+        ga.sample_stride = P.sample_stride;
+        ga.cand = cand;
+        ga.cnt = cnt;
         h0->stats[6]++;
     }
+    auto scan = [&](int pass) -> int {
+        if (P.mfma) {
+            ma.row_end = pass == 0 ? qd[0].n_sample : (pass == 1 ? qd[0].n_mid : h0->n_rows);
+            return qreg ? crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st) : crag_launch_scan_mfma(ma, pass ? 1 : 0, st);
+        }
+        return crag_launch_scan_gemv(ga, pass, P.nq_template, P.blocks[pass], st);
+    };
+    if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
+    // level 0: dense sample -> tau0
+    if (scan(0)) return fail(CRAG_E_HIP, "sample scan launch failed");
+    {
+        KthArgs k;
+        k.src = sample;
+        if (P.mfma && qreg) {
+            k.q_stride = 1;
+            k.e_stride = bpad;
+        } else {
+            k.q_stride = P.sample_stride;
+            k.e_stride = 1;
+        }
+        k.off0 = 0;
+        k.qd = qd_dev;
+        k.cnt = nullptr;
+        k.cnt_reset = nullptr;
+        k.B = B;
+        k.M = P.M;
+        k.tau = tau;
+        if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
+    }
+    // level 1: filtered scan of the first n1 rows -> tau1 (tightens tau0; never loosens it)
+    if (P.need_mid) {
+        if (scan(1)) return fail(CRAG_E_HIP, "level-1 scan launch failed");
+        KthArgs k;
+        k.src = (const uint32_t*)cand;
+        k.q_stride = 2LL * CRAG_CAND_CAP;
+        k.e_stride = 2;
+        k.off0 = 1;  // high word of the 64-bit key = ordered score
+        k.qd = qd_dev;
+        k.cnt = cnt;
+        k.cnt_reset = cnt;
+        k.B = B;
+        k.M = P.M;
+        k.tau = tau;
+        if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 1) launch failed");
+    }
+    if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
+    // level 2: the full scan
+    if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
+    if (scan(2)) return fail(CRAG_E_HIP, "full scan launch failed");
+    if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
     FinalizeArgs f;
     f.qd = qd_dev;
     f.queries = q_dev;
@@ -672,6 +723,7 @@ int crag_index_create(int dim, int dtype, int metric, int device, crag_index** o
     h->chunks = chunks;
     h->dim_pad = (int)((size_t)chunks * 16 / esz);
     h->len_present.assign(65536 + 1, 0);
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = h;
     return 0;
 }
@@ -870,6 +922,8 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     if ((rc = stage_device_queries(h, queries_dev, B, ws, st, &q))) return rc;
     const long long n = h->n_rows;
     const long long stride = n;
+    bool rowmajor = false;
+    long long bpad = B;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)std::max<long long>(stride, 1)))) return rc;
     if (path == 2) {
         if (h->dtype != CRAG_BF16) return fail(CRAG_E_INVALID, "mfma path needs a bf16 collection");
@@ -886,7 +940,16 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.metric = h->metric;
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = stride;
-        if (crag_launch_scan_mfma(a, 0, st)) return fail(CRAG_E_HIP, "mfma launch failed");
+        if (crag_qreg_supported(h->dim_pad)) {
+            rowmajor = true;
+            bpad = ((long long)B + 15) / 16 * 16;
+            if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)std::max<long long>(n, 1)))) return rc;
+            a.sample = (uint32_t*)ws->sample.p;
+            a.sample_stride = bpad;
+            if (crag_launch_scan_qreg(a, 0, h->n_cus, st)) return fail(CRAG_E_HIP, "qreg launch failed");
+        } else if (crag_launch_scan_mfma(a, 0, st)) {
+            return fail(CRAG_E_HIP, "mfma launch failed");
+        }
     } else {
         std::vector<GroupDesc> gd;
         int blk = 0;
@@ -922,10 +985,12 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     }
     HIPCHK(hipStreamSynchronize(st));
     // keys -> floats on the host side of the boundary is the caller's job; here we decode on the host
-    std::vector<uint32_t> keys((size_t)B * (size_t)n);
+    std::vector<uint32_t> keys((size_t)(rowmajor ? bpad : B) * (size_t)n);
     HIPCHK(hipMemcpy(keys.data(), ws->sample.p, keys.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<float> sc(keys.size());
-    for (size_t i = 0; i < keys.size(); ++i) sc[i] = crag_fkey_inv(keys[i]);
+    std::vector<float> sc((size_t)B * (size_t)n);
+    for (int b = 0; b < B; ++b)
+        for (long long i = 0; i < n; ++i)
+            sc[(size_t)b * n + i] = crag_fkey_inv(rowmajor ? keys[(size_t)i * bpad + b] : keys[(size_t)b * n + i]);
     HIPCHK(hipMemcpy(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }

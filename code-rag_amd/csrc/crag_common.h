@@ -33,10 +33,11 @@ struct GroupDesc {
     const void* rows;
     const float* xnorm;
     long long n_rows;
-    long long n_sample;  // rows [0, n_sample) form the dense threshold sample
+    long long n_sample;  // level 0: rows [0, n_sample) are scored densely
+    long long n_mid;     // level 1: rows [0, n_mid) are scanned with tau0 (== n_sample: no level 1)
     int q_first, nq;
-    int blk_first[2];  // [0] sample pass, [1] filter pass
-    int n_blk[2];
+    int blk_first[3];  // per pass: 0 dense sample, 1 level-1 filter, 2 full filter
+    int n_blk[3];
 };
 
 // Everything the per-query kernels need (one per query of the batch).
@@ -47,6 +48,7 @@ struct QueryDesc {
     const unsigned char* path_class;      // may be null
     long long n_rows;
     long long n_sample;
+    long long n_mid;
     long long id_base;
     float max_xnorm;
     int pad;
@@ -68,7 +70,7 @@ __host__ __device__ constexpr int crag_gcd(int a, int b) { return b == 0 ? a : c
 __host__ __device__ constexpr int crag_lcm(int a, int b) { return a / crag_gcd(a, b) * b; }
 
 // candidate buffer and sort limits of the select stage
-#define CRAG_CAND_CAP 8192
+#define CRAG_CAND_CAP 16384
 #define CRAG_MAX_M 512      // rescored candidates per query (2*top_k + slack) upper limit
 #define CRAG_MAX_KC 400     // 2*top_k upper limit
 #define CRAG_MAX_GROUP_Q 8  // queries per GEMV group
@@ -87,7 +89,8 @@ struct ScanArgs {
     unsigned long long* cand;  // [B][CRAG_CAND_CAP]
     uint32_t* cnt;             // [B]
 };
-int crag_launch_scan_gemv(const ScanArgs& a, int mode, int nq_template, int total_blocks, hipStream_t s);
+// pass: 0 dense sample of rows [0,n_sample), 1 filter rows [0,n_mid), 2 filter all rows
+int crag_launch_scan_gemv(const ScanArgs& a, int pass, int nq_template, int total_blocks, hipStream_t s);
 bool crag_gemv_supported(int dtype, int chunks);
 
 struct MfmaArgs {
@@ -106,11 +109,28 @@ struct MfmaArgs {
     uint32_t* cnt;
 };
 int crag_launch_scan_mfma(const MfmaArgs& a, int mode, hipStream_t s);
+// query-stationary MFMA scan (dim_pad in {256,384,512,768}); its sample is ROW-major [row][stride]
+bool crag_qreg_supported(int dim_pad);
+int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+
 
 int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n, float* xnorm, float* max_out,
                           hipStream_t s);
-int crag_launch_tau_select(const uint32_t* sample, long long sample_stride, const QueryDesc* qd, int B, int M,
-                           float* tau, hipStream_t s);
+// per query: tau = float of the M-th smallest ordered-score key of a strided list
+//   element i of query q = src[q*q_stride + off0 + i*e_stride]
+//   cnt == null: list length = qd[q].n_sample (dense sample); fewer than M+1 entries -> tau = +inf
+//   cnt != null: list length = min(cnt[q], CRAG_CAND_CAP) (candidate buffer); fewer than M -> tau kept
+//   cnt_reset != null: cnt_reset[q] = 0 afterwards
+struct KthArgs {
+    const uint32_t* src;
+    long long q_stride, e_stride, off0;
+    const QueryDesc* qd;
+    const uint32_t* cnt;
+    uint32_t* cnt_reset;
+    int B, M;
+    float* tau;
+};
+int crag_launch_kth(const KthArgs& a, hipStream_t s);
 struct FinalizeArgs {
     const QueryDesc* qd;
     const void* queries;

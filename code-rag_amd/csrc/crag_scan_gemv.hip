@@ -97,7 +97,7 @@ __device__ __forceinline__ float butterfly64(float (&v)[64], int lane) {
 
 template <int DT, int C, int NQ>
 __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__ groups, int n_groups,
-                                                   const uint4* __restrict__ queries, int mode, int metric,
+                                                   const uint4* __restrict__ queries, int pass, int metric,
                                                    const float* __restrict__ tau, uint32_t* __restrict__ sample,
                                                    long long sample_stride, unsigned long long* __restrict__ cand,
                                                    uint32_t* __restrict__ cnt) {
@@ -114,13 +114,14 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     const int bid = blockIdx.x;
 
     // block -> group (groups are few; blk_first ascending)
+    const int mode = pass != 0;  // 0 dense sample, 1 filter
     int g = 0;
-    while (g + 1 < n_groups && bid >= groups[g + 1].blk_first[mode]) ++g;
+    while (g + 1 < n_groups && bid >= groups[g + 1].blk_first[pass]) ++g;
     const GroupDesc* __restrict__ gp = groups + g;
-    const long long R = mode ? gp->n_rows : gp->n_sample;
+    const long long R = pass == 0 ? gp->n_sample : (pass == 1 ? gp->n_mid : gp->n_rows);
     const long long n_st = (R + RT - 1) / RT;
-    const int n_waves = gp->n_blk[mode] * 4;
-    const int w = (bid - gp->blk_first[mode]) * 4 + wave;
+    const int n_waves = gp->n_blk[pass] * 4;
+    const int w = (bid - gp->blk_first[pass]) * 4 + wave;
     const int nq = gp->nq;  // real queries in this group (<= NQ); the rest are padding
     const int q_first = gp->q_first;
     const float* __restrict__ xnorm = gp->xnorm;
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
 }
 
 template <int DT, int C>
-int launch_nq(const ScanArgs& a, int mode, int nqt, int blocks, hipStream_t s) {
+int launch_nq(const ScanArgs& a, int pass, int nqt, int blocks, hipStream_t s) {
 #define CRAG_GO(NQ)                                                                                              \
     hipLaunchKernelGGL((k_scan_gemv<DT, C, NQ>), dim3(blocks), dim3(256), 0, s, a.groups, a.n_groups,            \
-                       (const uint4*)a.queries, mode, a.metric, a.tau, a.sample, a.sample_stride, a.cand, a.cnt)
+                       (const uint4*)a.queries, pass, a.metric, a.tau, a.sample, a.sample_stride, a.cand, a.cnt)
     switch (nqt) {
         case 1: CRAG_GO(1); break;
         case 2: CRAG_GO(2); break;
@@ -219,15 +220,15 @@ int launch_nq(const ScanArgs& a, int mode, int nqt, int blocks, hipStream_t s) {
 }
 
 template <int DT>
-int launch_c(const ScanArgs& a, int mode, int nqt, int blocks, hipStream_t s) {
+int launch_c(const ScanArgs& a, int pass, int nqt, int blocks, hipStream_t s) {
     switch (a.chunks) {
-        case 32: return launch_nq<DT, 32>(a, mode, nqt, blocks, s);
-        case 48: return launch_nq<DT, 48>(a, mode, nqt, blocks, s);
-        case 64: return launch_nq<DT, 64>(a, mode, nqt, blocks, s);
-        case 96: return launch_nq<DT, 96>(a, mode, nqt, blocks, s);
-        case 128: return launch_nq<DT, 128>(a, mode, nqt, blocks, s);
-        case 192: return launch_nq<DT, 192>(a, mode, nqt, blocks, s);
-        case 256: return launch_nq<DT, 256>(a, mode, nqt, blocks, s);
+        case 32: return launch_nq<DT, 32>(a, pass, nqt, blocks, s);
+        case 48: return launch_nq<DT, 48>(a, pass, nqt, blocks, s);
+        case 64: return launch_nq<DT, 64>(a, pass, nqt, blocks, s);
+        case 96: return launch_nq<DT, 96>(a, pass, nqt, blocks, s);
+        case 128: return launch_nq<DT, 128>(a, pass, nqt, blocks, s);
+        case 192: return launch_nq<DT, 192>(a, pass, nqt, blocks, s);
+        case 256: return launch_nq<DT, 256>(a, pass, nqt, blocks, s);
         default: return -1;
     }
 }
@@ -240,8 +241,8 @@ bool crag_gemv_supported(int dtype, int chunks) {
            chunks == 256;
 }
 
-int crag_launch_scan_gemv(const ScanArgs& a, int mode, int nq_template, int total_blocks, hipStream_t s) {
+int crag_launch_scan_gemv(const ScanArgs& a, int pass, int nq_template, int total_blocks, hipStream_t s) {
     if (total_blocks <= 0) return 0;
-    return a.dtype == CRAG_BF16 ? launch_c<CRAG_BF16>(a, mode, nq_template, total_blocks, s)
-                                : launch_c<CRAG_F32>(a, mode, nq_template, total_blocks, s);
+    return a.dtype == CRAG_BF16 ? launch_c<CRAG_BF16>(a, pass, nq_template, total_blocks, s)
+                                : launch_c<CRAG_F32>(a, pass, nq_template, total_blocks, s);
 }

@@ -56,66 +56,52 @@ __global__ __launch_bounds__(256) void k_row_norms(const uint4* __restrict__ row
 }
 
 // ----------------------------------------------------------------------------------------
-// block-wide helpers (1024 threads)
-__device__ __forceinline__ void find_bin_256(unsigned int* hist, unsigned int* sh, unsigned int want) {
-    // hist[256] in LDS; finds bin b with prefix(b) < want <= prefix(b)+hist[b]; writes sh[0]=b, sh[1]=want-prefix(b)
-    const int t = threadIdx.x;
-    __shared__ unsigned int wsum[4];
-    unsigned int v = 0, incl = 0;
-    if (t < 256) {
-        v = hist[t];
-        incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int o = __shfl_up(incl, off);
-            if ((t & 63) >= off) incl += o;
-        }
-        if ((t & 63) == 63) wsum[t >> 6] = incl;
-    }
-    __syncthreads();
-    if (t < 256) {
-        unsigned int base = 0;
-        for (int k = 0; k < (t >> 6); ++k) base += wsum[k];
-        incl += base;
-        const unsigned int excl = incl - v;
-        if (v != 0 && excl < want && want <= incl) {
-            sh[0] = (unsigned int)t;
-            sh[1] = want - excl;
+// bitonic sort of P (power of two) 32-bit keys in LDS, ascending
+__device__ __forceinline__ void bitonic_sort_u32(uint32_t* s, int P) {
+    const int T = blockDim.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < (P >> 1); i += T) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int b = a | j;
+                const bool up = (a & k) == 0;
+                const uint32_t x = s[a], y = s[b];
+                if ((x > y) == up) {
+                    s[a] = y;
+                    s[b] = x;
+                }
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
 }
 
-// per query: tau = M-th smallest ordered key among the first n_sample scores
-__global__ __launch_bounds__(1024) void k_tau_select(const uint32_t* __restrict__ sample, long long stride,
-                                                     const QueryDesc* __restrict__ qd, int M,
-                                                     float* __restrict__ tau) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned int sh[2];
+// per query: tau = score of the M-th smallest ordered key of a strided list (KthArgs in crag_common.h)
+__global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* keys = (uint32_t*)smem;
     const int q = blockIdx.x;
-    const long long n = qd[q].n_sample;
-    if (n <= (long long)M) {  // every row is a candidate
-        if (threadIdx.x == 0) tau[q] = __builtin_inff();
-        return;
+    const bool from_cand = a.cnt != nullptr;
+    long long n;
+    if (from_cand) {
+        const unsigned int c = a.cnt[q];
+        n = c < CRAG_CAND_CAP ? c : CRAG_CAND_CAP;  // an overflowed buffer still holds CAP rows <= the old tau
+    } else {
+        n = a.qd[q].n_sample;
     }
-    const uint32_t* __restrict__ keys = sample + (long long)q * stride;
-    uint32_t prefix = 0, mask = 0;
-    unsigned int want = (unsigned int)M;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-        __syncthreads();
-        for (long long i = threadIdx.x; i < n; i += 1024) {
-            const uint32_t k = keys[i];
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        find_bin_256(hist, sh, want);
-        prefix |= sh[0] << shift;
-        mask |= 255u << shift;
-        want = sh[1];
-        __syncthreads();
+    __syncthreads();
+    if (a.cnt_reset && threadIdx.x == 0) a.cnt_reset[q] = 0;
+    if (n < (long long)a.M || (!from_cand && n == (long long)a.M)) {
+        if (!from_cand && threadIdx.x == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
+        return;                                                            // from_cand: keep the looser tau
     }
-    if (threadIdx.x == 0) tau[q] = crag_fkey_inv(prefix);
+    int P = 64;
+    while (P < n) P <<= 1;
+    const uint32_t* __restrict__ src = a.src + (long long)q * a.q_stride + a.off0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = i < n ? src[(long long)i * a.e_stride] : 0xffffffffu;
+    __syncthreads();
+    bitonic_sort_u32(keys, P);
+    if (threadIdx.x == 0) a.tau[q] = crag_fkey_inv(keys[a.M - 1]);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -455,9 +441,9 @@ int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n,
     return (int)hipGetLastError();
 }
 
-int crag_launch_tau_select(const uint32_t* sample, long long sample_stride, const QueryDesc* qd, int B, int M,
-                           float* tau, hipStream_t s) {
-    hipLaunchKernelGGL(k_tau_select, dim3(B), dim3(1024), 0, s, sample, sample_stride, qd, M, tau);
+int crag_launch_kth(const KthArgs& a, hipStream_t s) {
+    const size_t lds = sizeof(uint32_t) * CRAG_CAND_CAP;
+    hipLaunchKernelGGL(k_kth, dim3(a.B), dim3(1024), lds, s, a);
     return (int)hipGetLastError();
 }
 

@@ -228,7 +228,7 @@ int add_common(crag_index* h, const void* rows, int64_t n, const uint64_t* name_
 // filtered scan of the first n1 rows with tau0, level 2 = filtered scan of all rows with tau1.
 // tau_l = M-th smallest score of level l's rows, so at least M rows pass every filter; expected
 // candidates per query: M*n1/n0 at level 1 and M*N/n1 at level 2, balanced by n1 = sqrt(n0*N).
-long long level0_rows(long long N, int M) { return std::min<long long>(N, M <= 64 ? 4096 : 16384); }
+long long level0_rows(long long N, int M) { return std::min<long long>(N, M <= 64 ? 8192 : 16384); }
 long long level1_rows(long long N, long long n0, int M) {
     if (N <= n0) return n0;
     if ((double)M * (double)N / (double)n0 <= CRAG_CAND_CAP / 8) return n0;  // level 2 alone is cheap enough

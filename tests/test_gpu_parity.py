@@ -143,6 +143,29 @@ def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     assert st["mfma_batches"] >= 1
 
 
+@pytest.mark.parametrize("dtype,d,nq,path", [("f32", 384, 3, "gemv"), ("bf16", 768, 8, "gemv"), ("bf16", 768, 40, "mfma"),
+                                              ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma")])
+def test_scan_error_bound(dtype, d, nq, path):
+    """The certificate assumes |approximate scan score - exact score| <= eps with
+    eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every
+    (query, row) pair -- this also pins every lane->(row, query) mapping of both scan kernels."""
+    import torch
+    n = 2311
+    rows = O.synth_unit_rows(n, d, 1, dtype)
+    qs = O.synth_unit_rows(nq, d, 2, dtype)
+    col = make_collection(rows, dtype)
+    q = torch.from_numpy(qs).cuda() if dtype == "f32" else torch.from_numpy(qs.view(np.int16)).cuda().view(torch.bfloat16)
+    got = col.debug_dense_scores(q, path).cpu().numpy().astype(np.float64)
+    X, Q = O.as_f64(rows), O.as_f64(qs)
+    ref = (X * X).sum(1)[None, :] - 2.0 * Q @ X.T
+    xmax = float((X * X).sum(1).max())
+    qn = np.sqrt((Q * Q).sum(1))
+    eps = 2.0 * 2.0 ** -24 * (2.0 * (col.dim_pad + 4) * qn * np.sqrt(xmax) + 3.0 * xmax)
+    err = np.abs(got - ref).max(axis=1)
+    assert np.all(err <= eps), (err.max(), eps.min())
+    assert err.max() < 2e-6          # typical error is ~1e-7: the bound has three orders of margin
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 19, 20, 21, 63, 64, 65, 127, 129, 4095, 4097])
 def test_small_and_ragged_collections(coracle, n):
     rows, queries, classes, _ = synth_case(n, 384, "f32", 2, seed=5)

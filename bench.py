@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the extra regimes")
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     args = ap.parse_args()
 
     import numpy as np
@@ -223,7 +223,7 @@ def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
     coracle.build()
     m = min(sample_rows, n)
     host_rows = rows[:m].view(torch.int16).cpu().numpy().view(np.uint16)
-    nq = 16
+    nq = 256
     host_q = q[:nq].view(torch.int16).cpu().numpy().view(np.uint16)
     coracle.knn_fast_f32(host_rows[:10000], host_q[:1], 2 * top_k)  # warm the library
     t0 = time.perf_counter()

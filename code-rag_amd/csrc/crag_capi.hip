@@ -247,10 +247,20 @@ struct Plan {
     bool need_mid = false;
 };
 
+// where the single-GPU entry points want the reranked results (stage 2 launched optimistically right
+// behind stage 1, before the host looks at the certificates; re-launched if a fallback patched entries)
+struct MergeOut {
+    double symbol_boost;
+    long long* ids;
+    double* scores;
+    float* dist;
+    int* counts;
+};
+
 // one batch on one device: queries already on the device in index dtype, row stride dim_pad
 int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                    const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
-                   hipStream_t st) {
+                   hipStream_t st, const MergeOut* mo = nullptr) {
     crag_index* h0 = hs[0];
     Plan P;
     P.B = B;
@@ -458,6 +468,13 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     f.entries = entries_dev;
     f.status = status;
     if ((rc = crag_launch_finalize(f, st))) return fail(CRAG_E_HIP, "finalize launch failed");
+    auto merge = [&]() -> int {
+        if (!mo) return 0;
+        return crag_launch_merge_rerank(entries_dev, 1, B, P.kc, top_k, mo->symbol_boost, mo->ids, mo->scores, mo->dist,
+                                        mo->counts, st);
+    };
+    if (merge()) return fail(CRAG_E_HIP, "merge_rerank launch failed");
+    bool patched = false;
 
     // ---- verify: every query must carry an exactness certificate ----
     std::vector<uint32_t> hst((size_t)B);
@@ -534,7 +551,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         HIPCHK(hipMemcpyAsync(&s2, status + b, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (s2 != CRAG_ST_OK) return fail(CRAG_E_HIP, "exact fallback did not produce a certified result");
+        patched = true;
     }
+    if (patched && merge()) return fail(CRAG_E_HIP, "merge_rerank launch failed");
     return 0;
 }
 
@@ -645,15 +664,15 @@ int search_host(crag_index* const* hs, bool same, const float* queries, int B, i
     }
     if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * kc))) return rc;
     if ((rc = ws->out.ensure(out_bytes))) return rc;
-    rc = search_entries(hs, same, ws->q.p, B, top_k, qh_dev, qo_dev, (CragEntry*)ws->entries.p, ws, st);
-    if (rc) return rc;
     char* o = (char*)ws->out.p;
-    long long* d_ids = (long long*)o;
-    double* d_sc = (double*)(o + (size_t)B * top_k * 8);
-    float* d_di = (float*)(o + (size_t)B * top_k * 16);
-    int* d_cn = (int*)(o + (size_t)B * top_k * 20);
-    if ((rc = crag_launch_merge_rerank((const CragEntry*)ws->entries.p, 1, B, kc, top_k, symbol_boost, d_ids, d_sc, d_di, d_cn, st)))
-        return fail(CRAG_E_HIP, "merge_rerank launch failed");
+    MergeOut mo;
+    mo.symbol_boost = symbol_boost;
+    mo.ids = (long long*)o;
+    mo.scores = (double*)(o + (size_t)B * top_k * 8);
+    mo.dist = (float*)(o + (size_t)B * top_k * 16);
+    mo.counts = (int*)(o + (size_t)B * top_k * 20);
+    rc = search_entries(hs, same, ws->q.p, B, top_k, qh_dev, qo_dev, (CragEntry*)ws->entries.p, ws, st, &mo);
+    if (rc) return rc;
     char* ho = (char*)ws->pinned + o_off;
     HIPCHK(hipMemcpyAsync(ho, o, out_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -890,12 +909,15 @@ int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k,
     const void* q = nullptr;
     if ((rc = stage_device_queries(h, queries_dev, B, ws, st, &q))) return rc;
     if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * 2 * top_k))) return rc;
-    rc = search_entries(hs.data(), true, q, B, top_k, q_hashes_dev, q_hash_off_dev, (CragEntry*)ws->entries.p, ws, st);
+    MergeOut mo;
+    mo.symbol_boost = symbol_boost;
+    mo.ids = (long long*)out_ids_dev;
+    mo.scores = out_scores_dev;
+    mo.dist = out_dist_dev;
+    mo.counts = out_counts_dev;
+    rc = search_entries(hs.data(), true, q, B, top_k, q_hashes_dev, q_hash_off_dev, (CragEntry*)ws->entries.p, ws, st, &mo);
     if (rc) return rc;
-    rc = crag_launch_merge_rerank((const CragEntry*)ws->entries.p, 1, B, 2 * top_k, top_k, symbol_boost,
-                                  (long long*)out_ids_dev, out_scores_dev, out_dist_dev, out_counts_dev, st);
-    if (rc) return fail(CRAG_E_HIP, "merge_rerank launch failed");
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st));  // only non-trivial after a fallback re-merge
     return 0;
 }
 

@@ -180,6 +180,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         line["regimes"] = extra_regimes(col, q, n, d, torch)
         line["cpu_baseline"] = cpu_baseline(rows, q, n, d, top_k, args.cpu_sample_rows, torch, np)
+        col.close()
+        del col, rows, name_hash, path_class
+        torch.cuda.empty_cache()
+        line["regimes"] += config_regimes(ch, torch, np, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -212,6 +216,79 @@ def extra_regimes(col, q, n, d, torch):
                     "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                     "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
     col.set_path("auto")
+    return out
+
+
+def config_regimes(ch, torch, np, dev):
+    """BASELINE.json configs[1] (1M x 384 fp32, batch-1, top-10) and configs[4] (10M x 1024 bf16 in 64
+    workspace-isolated collections with symbol/path metadata, one query per collection per batch)."""
+    out = []
+    g = torch.Generator(device=dev).manual_seed(4321)
+
+    def unit(nr, dd, dtype):
+        x = torch.randn((nr, dd), generator=g, device=dev, dtype=torch.float32)
+        return (x / x.norm(dim=1, keepdim=True)).to(dtype).contiguous()
+
+    # ---- configs[1]
+    n2, d2 = 1_000_000, 384
+    c2 = ch.GpuCollection(d2, "f32", "l2", device=dev.index)
+    r2 = unit(n2, d2, torch.float32)
+    c2.attach_device(r2)
+    c2.finalize()
+    q2 = unit(64, d2, torch.float32)
+    for i in range(3):
+        c2.search_device(q2[i:i + 1], 10, 2.0)
+    c2.profile(reset=True)
+    c2.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(50):
+        c2.search_device(q2[i:i + 1], 10, 2.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pr = c2.profile(reset=True)
+    ms = pr["filter_scan_ms"] / max(pr["searches"], 1)
+    gbs = (n2 * d2 * 4 + n2 * 4) / (ms * 1e-3) / 1e9
+    out.append({"regime": "configs[1]: 1M x 384 fp32, batch-1 top-10 GEMV", "queries_per_s": round(50 / dt, 2),
+                "ms_per_batch": round(dt / 50 * 1e3, 4), "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1),
+                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+    c2.close()
+    del r2
+    # ---- configs[4]: 64 collections x 156,250 rows x 1024 bf16 (10M rows in total)
+    ncol, nper, d5 = 64, 156_250, 1024
+    n_sym = 50_000
+    sym_hash, sym_len = ch.hash_names([f"sym{i}" for i in range(n_sym)])
+    sym_hash_t = torch.from_numpy(sym_hash.view(np.int64)).to(dev)
+    cols, keep = [], []
+    for c in range(ncol):
+        rr = unit(nper, d5, torch.bfloat16)
+        zipf = (torch.rand((nper,), generator=g, device=dev).pow(3.0) * n_sym).long().clamp_(max=n_sym - 1)
+        nh = sym_hash_t[zipf].contiguous()
+        u = torch.rand((nper,), generator=g, device=dev)
+        pc = torch.where(u < 0.70, 0, torch.where(u < 0.95, 2, 1)).to(torch.uint8).contiguous()
+        col = ch.GpuCollection(d5, "bf16", "l2", device=dev.index)
+        col.attach_device(rr, nh, pc)
+        col.set_symbols(sym_hash, sym_len)
+        col.finalize()
+        cols.append(col)
+        keep.append((rr, nh, pc))
+    rng = np.random.default_rng(5)
+    q5 = unit(ncol, d5, torch.float32).cpu().numpy()
+    texts = [f"where is sym{int(rng.integers(0, n_sym))} used together with sym{int(rng.integers(0, n_sym))}?" for _ in range(ncol)]
+    for _ in range(2):
+        ch.search_multi(cols, q5, 8, 2.0, texts)
+    t0 = time.perf_counter()
+    steps = 10
+    for _ in range(steps):
+        ch.search_multi(cols, q5, 8, 2.0, texts)
+    dt = time.perf_counter() - t0
+    byts = ncol * nper * (d5 * 2 + 4)
+    out.append({"regime": "configs[4]: 64 collections x 156250 x 1024 bf16, one query each, top-8, symbolBoost rerank "
+                          "(host-buffer entry point, PCIe included)", "queries_per_s": round(ncol * steps / dt, 2),
+                "ms_per_batch": round(dt / steps * 1e3, 4), "hbm_GBps": round(byts / (dt / steps) / 1e9, 1),
+                "hbm_frac": round(byts / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)})
+    for col in cols:
+        col.close()
     return out
 
 

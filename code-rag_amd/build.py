@@ -7,6 +7,7 @@ One object per .hip file (compiled in parallel), then one shared library.  No CP
 built: the library refuses devices that are not gfx950.
 """
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -15,7 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_select.hip", "crag_capi.hip"]
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_scan_qreg2.hip", "crag_select.hip",
+           "crag_capi.hip"]
+INCLUDES = {"crag_scan_qreg.hip": ["crag_qreg_kloop.inc"], "crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,6 +27,42 @@ def _newer(target, deps):
         return False
     t = os.path.getmtime(target)
     return all(os.path.getmtime(d) <= t for d in deps)
+
+
+_REG = re.compile(r"\b([av])(?:(\d+)\b|\[(\d+):(\d+)\])")
+
+
+def check_qreg2_isa(asm_path):
+    """crag_scan_qreg2.hip keeps its query fragments in fixed registers the compiler is not told about
+    (gen_qreg2_kloop.py: all AGPRs, and v[128:255] at KS = 48).  The generated statements list them as
+    clobbers, so nothing of the compiler's lives there ACROSS a statement; this check proves on the
+    emitted ISA that no compiler-generated instruction touches them BETWEEN statements either."""
+    kernel, in_asm, bad, seen = None, False, [], set()
+    for n, line in enumerate(open(asm_path), 1):
+        m = re.match(r"^(_Z\S*k_scan_qreg2ILi(\d+)ELi\d+E\S*):", line)
+        if m:
+            kernel, ks, in_asm = m.group(1), int(m.group(2)), False
+            seen.add(kernel)
+            continue
+        if kernel is None:
+            continue
+        if "s_endpgm" in line:
+            kernel = None
+            continue
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        elif not in_asm:
+            code = line.split(";")[0]
+            for f, one, lo, hi in _REG.findall(code):
+                top = int(one) if one else int(hi)
+                if f == "a" or (ks == 48 and top >= 128):
+                    bad.append(f"{asm_path}:{n}: {line.strip()}")
+    if len(seen) < 8:
+        raise RuntimeError(f"check_qreg2_isa: expected 8 k_scan_qreg2 kernels in {asm_path}, found {len(seen)}")
+    if bad:
+        raise RuntimeError("check_qreg2_isa: compiler code touches the fixed fragment registers:\n" + "\n".join(bad[:20]))
 
 
 def build(force=False, verbose=True):
@@ -36,8 +75,10 @@ def build(force=False, verbose=True):
         src = os.path.join(SRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or not _newer(obj, [src] + headers):
+        if force or not _newer(obj, [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]):
             jobs.append(["hipcc"] + FLAGS + ["-c", src, "-o", obj])
+            if s == "crag_scan_qreg2.hip":  # device ISA of the same compilation, for check_qreg2_isa
+                jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", os.path.join(OBJ, "crag_scan_qreg2.s")])
 
     def run(cmd):
         if verbose:
@@ -47,6 +88,7 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
+    check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
     if jobs or not os.path.exists(LIB):
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -402,7 +402,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     auto scan = [&](int pass) -> int {
         if (P.mfma) {
             ma.row_end = pass == 0 ? qd[0].n_sample : (pass == 1 ? qd[0].n_mid : h0->n_rows);
-            return qreg ? crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st) : crag_launch_scan_mfma(ma, pass ? 1 : 0, st);
+            if (!qreg) return crag_launch_scan_mfma(ma, pass ? 1 : 0, st);
+            return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
+                                      : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
         }
         return crag_launch_scan_gemv(ga, pass, P.nq_template, P.blocks[pass], st);
     };
@@ -968,7 +970,8 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
             if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)std::max<long long>(n, 1)))) return rc;
             a.sample = (uint32_t*)ws->sample.p;
             a.sample_stride = bpad;
-            if (crag_launch_scan_qreg(a, 0, h->n_cus, st)) return fail(CRAG_E_HIP, "qreg launch failed");
+            if (B > 128 ? crag_launch_scan_qreg2(a, 0, h->n_cus, st) : crag_launch_scan_qreg(a, 0, h->n_cus, st))
+                return fail(CRAG_E_HIP, "qreg launch failed");
         } else if (crag_launch_scan_mfma(a, 0, st)) {
             return fail(CRAG_E_HIP, "mfma launch failed");
         }

@@ -112,6 +112,8 @@ int crag_launch_scan_mfma(const MfmaArgs& a, int mode, hipStream_t s);
 // query-stationary MFMA scan (dim_pad in {256,384,512,768}); its sample is ROW-major [row][stride]
 bool crag_qreg_supported(int dim_pad);
 int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// same contract, 256 queries per workgroup (two 32-query blocks per wave): the choice for B > 128
+int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 
 
 int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n, float* xnorm, float* max_out,

@@ -1,0 +1,289 @@
+// K2 (two-block query-stationary form): MFMA scan for 129 <= B query batches, bf16, dim_pad <= 768, gfx950.
+//
+// Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
+// /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
+//
+// Same dataflow as crag_scan_qreg.hip (queries never move, 32-row corpus tiles stream HBM -> LDS by
+// LDS-DMA through a ring of three buffers, one wave per SIMD, fused threshold filter), but a wave
+// holds TWO 32-query blocks, so a workgroup owns 256 queries and every A fragment read from LDS
+// feeds two MFMAs: per MFMA half the LDS-DMA instructions, half the L2 -> LDS bytes and half the
+// LDS reads, and the two accumulator chains alternate in the matrix pipe.  The 96 query fragments of
+// D = 768 (384 registers) do not fit the 256 AGPRs: 64 live there, 32 in VGPRs (fixed registers outside
+// the compiler's allocation, see gen_qreg2_kloop.py and build.py's ISA check), and the accumulators
+// are VGPRs so that the filter reads them with plain VALU instructions.  The whole tile (K-loop,
+// prefetch of a later tile, the filter's fast path = minimum score of the lane's rows per block) is
+// one generated statement, crag_qreg2_kloop.inc (gen_qreg2_kloop.py holds the register contract).
+//
+//   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced)
+//   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
+#include "crag_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int Q2_TM = 32;      // corpus rows per tile
+constexpr int Q2_WAVES = 4;    // waves per workgroup: one per SIMD
+constexpr int Q2_QPW = 64;     // queries per wave: two MFMA blocks
+constexpr int Q2_QPB = Q2_WAVES * Q2_QPW;
+constexpr int Q2_NSTAGE = 3;   // LDS tile buffers
+constexpr int Q2_XN_BYTES = 256;
+
+// score = c * (q . x) + w * |x|^2   (l2: -2, 1; ip: -1, 0) and the LDS address of the lane's |x|^2 run
+struct Qreg2Epi {
+    float c, w;
+    unsigned xaddr;
+};
+
+template <int PPW>
+struct Qreg2Dma {
+    unsigned voff[PPW / 2];     // per-lane byte offset of this wave's piece i inside a 16-row half of the tile block
+    const unsigned char* tile;  // wave-uniform: first byte of the tile in the row matrix
+    const unsigned char* tile_hi;  // wave-uniform: first byte of the tile's rows 16..31
+    unsigned lds_dst;           // wave-uniform: LDS byte address of this wave's piece 0 in the target buffer
+    unsigned xoff;              // per-lane byte offset into the |x|^2 column (lane * 4)
+    const float* xn;            // wave-uniform: |x|^2 of the tile's first row
+    unsigned xn_dst;            // wave-uniform: LDS byte address of this wave's |x|^2 slot
+};
+
+#include "crag_qreg2_kloop.inc"
+
+// slow path of the filter for one query block: this lane's query has at least one passing row
+__device__ __forceinline__ void q2_append(const f32x16_t& acc, const f32x16_t& xs, float c, float tq, unsigned mb,
+                                          unsigned row_end, int q, unsigned long long* __restrict__ cand,
+                                          uint32_t* __restrict__ cnt) {
+    int npass = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
+        npass += (fmaf(c, acc[r], xs[r]) <= tq && m < row_end) ? 1 : 0;
+    }
+    if (!npass) return;
+    asm volatile("" : "+v"(q));  // address arithmetic stays on this rare path (not hoisted into live registers)
+    // one returning atomic per lane (= per query) for all of its passing rows
+    unsigned pos = atomicAdd(&cnt[q], (unsigned)npass);
+    unsigned long long* cq = cand + (long long)q * CRAG_CAND_CAP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
+        const float s = fmaf(c, acc[r], xs[r]);
+        if (s <= tq && m < row_end) {
+            if (pos < CRAG_CAND_CAP) cq[pos] = ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)m;
+            ++pos;
+        }
+    }
+}
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned short* __restrict__ rows,
+                                                                 const float* __restrict__ xnorm, long long row_end,
+                                                                 const unsigned short* __restrict__ queries, int n_queries,
+                                                                 int nqg, int metric, const float* __restrict__ tau,
+                                                                 uint32_t* __restrict__ sample, long long sample_stride,
+                                                                 unsigned long long* __restrict__ cand,
+                                                                 uint32_t* __restrict__ cnt) {
+    constexpr int C = KS * 2;                  // 16-byte chunks per row
+    constexpr int D = KS * 16;                 // elements per row
+    constexpr int ROWB = C * 16;               // bytes per row (a multiple of 256)
+    constexpr int STAGE = Q2_TM * ROWB;        // bytes per LDS tile buffer
+    constexpr int PIECES = Q2_TM * C / 64;     // 1-KiB DMA pieces per tile
+    constexpr int PPW = PIECES / Q2_WAVES;     // pieces per wave
+    constexpr int XN_BASE = Q2_NSTAGE * STAGE; // |x|^2 slots: [stage][wave][64 floats]
+    static_assert(PIECES % Q2_WAVES == 0, "pieces must split evenly over the waves");
+    static_assert(ROWB % 256 == 0, "the XOR address form needs 256-byte rows");
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];  // the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // workgroup -> (query group, row-tile stream); workgroups with equal blockIdx % 8 share an XCD
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int qg = j % nqg;
+    const int stream = j / nqg;
+    const int n_streams = (int)(gridDim.x >> 3) / nqg;
+    const long long n_tiles = (row_end + Q2_TM - 1) / Q2_TM;
+    const long long t_step = (long long)n_streams * 8;
+    long long t = (long long)stream * 8 + xcd;
+
+    const int q_base = qg * Q2_QPB + wave * Q2_QPW;
+    const bool wave_active = q_base < n_queries;  // wave-uniform
+    const int q0 = q_base + fr, q1 = q_base + 32 + fr;
+    const bool ok0 = q0 < n_queries, ok1 = q1 < n_queries;
+    // stationary B operands: this lane's two queries, k = 16 s + 8 fh + [0,8)
+    // (they live in fixed registers that only the generated statements name, see gen_qreg2_kloop.py)
+    Qreg2Load<KS>::run(queries + (long long)(ok0 ? q0 : n_queries - 1) * D + 8 * fh,
+                       queries + (long long)(ok1 ? q1 : n_queries - 1) * D + 8 * fh);
+    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
+    if (MODE == 1 && ok0) tq0 = tau[q0];
+    if (MODE == 1 && ok1) tq1 = tau[q1];
+
+    // LDS-DMA of one tile: 1-KiB pieces of the lane-linear image; linear 16-byte position P holds global
+    // chunk (row P / C, chunk (P % C) ^ (row & 15)).  A wave takes pieces wave + WAVES*i of each 16-row half
+    // of the tile: rows r and r + 16 swizzle alike, so both halves share one per-lane offset and differ in
+    // the scalar base.  Plus this wave's copy of |x|^2.  Every wave issues exactly PPW + 1 DMA instructions
+    // per tile (the counted waits rely on it).
+    constexpr int HP = PPW / 2;                 // pieces per wave and half
+    constexpr int HALF = 16 * ROWB;             // bytes per half tile (= KS / 2 pieces)
+    static_assert(PPW % 2 == 0 && (KS / 2) % Q2_WAVES == 0, "half tiles must split evenly over the waves");
+    unsigned voff[HP];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+        const int P = (wave + Q2_WAVES * i) * 64 + lane;
+        const int r = P / C, p = P - r * C;
+        voff[i] = (unsigned)(r * C + (p ^ (r & 15))) * 16u;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto issue = [&](long long tile, int buf) {
+        const long long row0 = tile * Q2_TM;
+        const unsigned char* tb = (const unsigned char*)rows + row0 * (long long)ROWB;
+        const bool whole = row0 + Q2_TM <= row_end;
+        const unsigned r_last = (unsigned)(row_end - 1 - row0);  // ragged tile only: its last valid row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < HP; ++i) {
+                unsigned off = voff[i] + h * HALF;
+                if (!whole) {  // ragged last tile: rows past the end re-read the last row (never past the matrix)
+                    asm volatile("" : "+v"(off));  // keep the row arithmetic here, not hoisted into live registers
+                    const unsigned r = off / ROWB;
+                    if (r > r_last) off -= (r - r_last) * ROWB;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + off),
+                                                 (__attribute__((address_space(3))) void*)(lds + buf * STAGE + h * HALF + (wave + Q2_WAVES * i) * 1024),
+                                                 16, 0, 0);
+            }
+        }
+        const float* gx = xnorm + row0 + lane;  // xnorm is padded by >= 256 floats
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
+                                         (__attribute__((address_space(3))) void*)(lds + XN_BASE + (buf * Q2_WAVES + wave) * Q2_XN_BYTES),
+                                         4, 0, 0);
+    };
+
+    // fragment address of k-step 0 in buffer 0 (see gen_qreg2_kloop.py), |x|^2 run of this lane in buffer 0
+    const unsigned a_lane = lds_base + fr * ROWB + ((fh ^ (fr & 15)) << 4);
+    const unsigned x_lane = lds_base + XN_BASE + wave * Q2_XN_BYTES + 16 * fh;
+    Qreg2Epi e;
+    e.c = metric == CRAG_L2 ? -2.f : -1.f;
+    e.w = metric == CRAG_L2 ? 1.f : 0.f;
+
+    // prologue: two tiles in flight, wait for the first
+    int cur = 0;
+    if (t < n_tiles) issue(t, 0);
+    if (t + t_step < n_tiles) {
+        issue(t + t_step, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    for (; t < n_tiles; t += t_step) {
+        const long long nt2 = t + 2 * t_step;
+        const bool more = nt2 < n_tiles;  // workgroup-uniform
+        int nxt2 = cur + 2;
+        if (nxt2 >= Q2_NSTAGE) nxt2 -= Q2_NSTAGE;
+        // prefetch tile t + 2 steps into the buffer of tile t - step (every wave left it before the last
+        // barrier): between the MFMAs of the K-loop when this wave multiplies and the tile is whole,
+        // up front otherwise
+        const bool dma_in_loop = more && wave_active && (nt2 + 1) * Q2_TM <= row_end;
+        if (more && !dma_in_loop) issue(nt2, nxt2);
+        if (wave_active) {
+            const unsigned a0 = a_lane + cur * STAGE;
+            e.xaddr = x_lane + cur * (Q2_WAVES * Q2_XN_BYTES);
+            f32x16_t acc0, acc1, xs;  // xs = w * |x|^2 of this lane's 16 rows (rows 8 g + 4 fh + e)
+            float mn0, mn1;
+            if (dma_in_loop) {
+                Qreg2Dma<PPW> d;
+#pragma unroll
+                for (int i = 0; i < HP; ++i) d.voff[i] = voff[i];
+                d.tile = (const unsigned char*)rows + nt2 * (long long)STAGE;
+                d.tile_hi = d.tile + HALF;
+                d.lds_dst = lds_base + nxt2 * STAGE + wave * 1024;
+                d.xoff = lane * 4;
+                d.xn = xnorm + nt2 * Q2_TM;
+                d.xn_dst = lds_base + XN_BASE + (nxt2 * Q2_WAVES + wave) * Q2_XN_BYTES;
+                Qreg2KLoop<KS, true>::run(acc0, acc1, xs, mn0, mn1, a0, e, d);
+            } else {
+                Qreg2KLoop<KS, false>::run(acc0, acc1, xs, mn0, mn1, a0, e);
+            }
+            const bool hit0 = mn0 <= tq0, hit1 = mn1 <= tq1;
+            if (MODE == 0 || __any(hit0 || hit1)) {
+                // row numbers fit 32 bits (rows per collection < 2^32, include/coderag_hip.h)
+                const unsigned mb = (unsigned)t * Q2_TM + 4 * fh, re = (unsigned)row_end;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
+                        if (m < re) {
+                            if (ok0) sample[m * sample_stride + q0] = crag_fkey(fmaf(e.c, acc0[r], xs[r]));
+                            if (ok1) sample[m * sample_stride + q1] = crag_fkey(fmaf(e.c, acc1[r], xs[r]));
+                        }
+                    }
+                } else {
+                    if (hit0) q2_append(acc0, xs, e.c, tq0, mb, re, q0, cand, cnt);
+                    if (hit1) q2_append(acc1, xs, e.c, tq1, mb, re, q1, cand, cnt);
+                }
+            }
+        }
+        // tile t + step must have landed in every wave's view before anyone reads it: each wave retires all
+        // but the DMA instructions it issued in THIS iteration (they are its youngest), then the barrier
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == Q2_NSTAGE ? 0 : cur + 1;
+    }
+}
+
+template <int KS>
+int launch_ks(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
+    const size_t lds = (size_t)Q2_NSTAGE * Q2_TM * KS * 2 * 16 + (size_t)Q2_NSTAGE * Q2_WAVES * Q2_XN_BYTES;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[mode]) {
+        if (mode == 0)
+            (void)hipFuncSetAttribute((const void*)k_scan_qreg2<KS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void*)k_scan_qreg2<KS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[mode] = true;
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL((k_scan_qreg2<KS, 0>), dim3(grid), dim3(64 * Q2_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
+                           a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
+                           a.sample_stride, a.cand, a.cnt);
+    else
+        hipLaunchKernelGGL((k_scan_qreg2<KS, 1>), dim3(grid), dim3(64 * Q2_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
+                           a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
+                           a.sample_stride, a.cand, a.cnt);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// sample layout of this kernel: sample[row * sample_stride + query]  (row-major), as crag_launch_scan_qreg
+int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
+    if (a.row_end <= 0 || a.n_queries <= 0) return 0;
+    const int nqg = (a.n_queries + Q2_QPB - 1) / Q2_QPB;
+    if (nqg > 32) return -1;
+    int streams = (n_cus / 8) / nqg;  // row-tile streams per XCD
+    if (streams < 1) streams = 1;
+    const long long n_tiles = (a.row_end + Q2_TM - 1) / Q2_TM;
+    while (streams > 1 && (long long)streams * 8 > n_tiles) --streams;
+    const int grid = 8 * streams * nqg;
+#ifdef Q2_ONLY_KS
+    return launch_ks<Q2_ONLY_KS>(a, mode, grid, nqg, s);
+#else
+    switch (a.dim_pad) {
+        case 256: return launch_ks<16>(a, mode, grid, nqg, s);
+        case 384: return launch_ks<24>(a, mode, grid, nqg, s);
+        case 512: return launch_ks<32>(a, mode, grid, nqg, s);
+        case 768: return launch_ks<48>(a, mode, grid, nqg, s);
+        default: return -1;
+    }
+#endif
+}

@@ -129,6 +129,10 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (1024, 5000, 33, 8, "l2"),
     (384, 8000, 64, 10, "ip"),
     (256, 300, 17, 10, "l2"),               # fewer rows than one sample tile
+    (512, 6000, 200, 10, "l2"),             # B > 128: two query blocks per wave
+    (384, 8000, 150, 10, "ip"),
+    (256, 3001, 257, 10, "l2"),             # second query group holds one query
+    (768, 20000, 300, 10, "ip"),
 ])
 def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)
@@ -144,7 +148,9 @@ def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
 
 
 @pytest.mark.parametrize("dtype,d,nq,path", [("f32", 384, 3, "gemv"), ("bf16", 768, 8, "gemv"), ("bf16", 768, 40, "mfma"),
-                                              ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma")])
+                                              ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma"),
+                                              ("bf16", 768, 150, "mfma"), ("bf16", 384, 129, "mfma"), ("bf16", 512, 256, "mfma"),
+                                              ("bf16", 256, 192, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

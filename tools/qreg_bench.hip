@@ -1,6 +1,12 @@
 // Ablation harness for the query-stationary MFMA scan (not part of the product): times
 // k_scan_qreg<48,1> on random data with tau = -inf (no appends).
+#ifdef USE_Q2
+#include "../code-rag_amd/csrc/crag_scan_qreg2.hip"
+#define LAUNCH crag_launch_scan_qreg2
+#else
 #include "../code-rag_amd/csrc/crag_scan_qreg.hip"
+#define LAUNCH crag_launch_scan_qreg
+#endif
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
@@ -18,9 +24,9 @@ int main(int argc, char** argv) {
     MfmaArgs a; a.rows = rows; a.xnorm = xn; a.n_rows = n; a.row_begin = 0; a.row_end = n; a.queries = q; a.n_queries = B;
     a.dim_pad = D; a.metric = CRAG_L2; a.tau = tau; a.sample = nullptr; a.sample_stride = 0; a.cand = cand; a.cnt = cnt;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) crag_launch_scan_qreg(a, 1, 256, nullptr);
+    for (int i = 0; i < 3; ++i) LAUNCH(a, 1, 256, nullptr);
     hipDeviceSynchronize();
-    hipEventRecord(e0); for (int i = 0; i < 10; ++i) crag_launch_scan_qreg(a, 1, 256, nullptr); hipEventRecord(e1);
+    hipEventRecord(e0); for (int i = 0; i < 10; ++i) LAUNCH(a, 1, 256, nullptr); hipEventRecord(e1);
     hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     printf("B=%d  %.3f ms  %.1f GB/s  %.1f TFLOP/s  (%s)\n", B, ms, n * D * 2.0 / ms / 1e6, 2.0 * B * n * D / ms / 1e9, hipGetErrorString(hipGetLastError()));
     return 0;

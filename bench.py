@@ -33,6 +33,16 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~630
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
+def pmc_traffic(n, d, B):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
+    (rocprofv3 cannot wrap itself; profiles/pmc_traffic.json says how it was taken), else None."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(f"{n}|{d}|{B}", {}).get("bytes")
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,13 +151,13 @@ def main():
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
     roofline = {
-        "kernel": "k_scan_mfma (filter pass)" if B >= 16 else "k_scan_gemv (filter pass)",
+        "kernel": ("k_scan_qreg2" if B > 128 else "k_scan_qreg" if B >= 9 else "k_scan_gemv") + " (filter pass over all rows)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,
         "unit": "GB/s" if hbm_bound else "TFLOP/s",
         "frac": round((achieved_gbs / HBM_PEAK_GBS) if hbm_bound else (flops / (scan_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF), 4),
-        "traffic": None,
+        "traffic": pmc_traffic(n, d, B),
         "kernel_ms": round(scan_ms, 4),
         "algorithmic_bytes": alg_bytes,
         "mfma_tflops": round(flops / (scan_ms * 1e-3) / 1e12, 2) if scan_ms > 0 else 0.0,

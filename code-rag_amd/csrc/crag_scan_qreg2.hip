@@ -47,7 +47,10 @@ struct Qreg2Dma {
     unsigned xn_dst;            // wave-uniform: LDS byte address of this wave's |x|^2 slot
 };
 
-#include "crag_qreg2_kloop.inc"
+#ifndef Q2_KLOOP_INC  // tools/qreg_bench.hip substitutes ablation builds of the statements
+#define Q2_KLOOP_INC "crag_qreg2_kloop.inc"
+#endif
+#include Q2_KLOOP_INC
 
 // slow path of the filter for one query block: this lane's query has at least one passing row
 __device__ __forceinline__ void q2_append(const f32x16_t& acc, const f32x16_t& xs, float c, float tq, unsigned mb,
@@ -181,6 +184,10 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     }
     __builtin_amdgcn_s_barrier();
 
+#ifdef Q2_PROFILE  // tools/qreg_bench.hip: time in the end-of-tile wait + barrier vs the whole loop (100 MHz ticks)
+    unsigned long long prof_wait = 0, prof_bar = 0;
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
     for (; t < n_tiles; t += t_step) {
         const long long nt2 = t + 2 * t_step;
         const bool more = nt2 < n_tiles;  // workgroup-uniform
@@ -206,9 +213,14 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                 d.xoff = lane * 4;
                 d.xn = xnorm + nt2 * Q2_TM;
                 d.xn_dst = lds_base + XN_BASE + (nxt2 * Q2_WAVES + wave) * Q2_XN_BYTES;
-                Qreg2KLoop<KS, true>::run(acc0, acc1, xs, mn0, mn1, a0, e, d);
+                switch (wave) {  // the DMA slots of the K-loop are staggered by wave
+                    case 0: Qreg2KLoop<KS, true, 0>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
+                    case 1: Qreg2KLoop<KS, true, 1>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
+                    case 2: Qreg2KLoop<KS, true, 2>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
+                    default: Qreg2KLoop<KS, true, 3>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
+                }
             } else {
-                Qreg2KLoop<KS, false>::run(acc0, acc1, xs, mn0, mn1, a0, e);
+                Qreg2KLoop<KS, false, 0>::run(acc0, acc1, xs, mn0, mn1, a0, e);
             }
             const bool hit0 = mn0 <= tq0, hit1 = mn1 <= tq1;
             if (MODE == 0 || __any(hit0 || hit1)) {
@@ -231,14 +243,33 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
         }
         // tile t + step must have landed in every wave's view before anyone reads it: each wave retires all
         // but the DMA instructions it issued in THIS iteration (they are its youngest), then the barrier
+#ifdef Q2_PROFILE
+        const unsigned long long prof_a = __builtin_readcyclecounter();
+#endif
         if (more) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifdef Q2_PROFILE
+        const unsigned long long prof_b = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef Q2_PROFILE
+        const unsigned long long prof_c = __builtin_readcyclecounter();
+        prof_wait += prof_b - prof_a;
+        prof_bar += prof_c - prof_b;
+#endif
         cur = cur + 1 == Q2_NSTAGE ? 0 : cur + 1;
     }
+#ifdef Q2_PROFILE
+    if (lane == 0) {
+        atomicAdd(&cnt[2000], (unsigned)prof_wait);
+        atomicAdd(&cnt[2001], (unsigned)prof_bar);
+        atomicAdd(&cnt[2002], (unsigned)(__builtin_readcyclecounter() - prof_t0));
+        atomicAdd(&cnt[2003], 1u);
+    }
+#endif
 }
 
 template <int KS>

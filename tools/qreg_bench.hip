@@ -14,12 +14,12 @@ int main(int argc, char** argv) {
     const long long n = 4000000; const int D = 768, B = argc > 1 ? atoi(argv[1]) : 256;
     unsigned short *rows, *q; float *xn, *tau; unsigned long long* cand; uint32_t* cnt;
     hipMalloc(&rows, n * D * 2); hipMalloc(&q, 1024 * D * 2); hipMalloc(&xn, (n + 512) * 4); hipMalloc(&tau, 1024 * 4);
-    hipMalloc(&cand, 1024ull * CRAG_CAND_CAP * 8); hipMalloc(&cnt, 4096);
+    hipMalloc(&cand, 1024ull * CRAG_CAND_CAP * 8); hipMalloc(&cnt, 16384);
     std::vector<unsigned short> h(8 << 20);
     for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));  // ~ +-0.01..0.03
     for (long long off = 0; off < n * D; off += h.size()) hipMemcpy(rows + off, h.data(), std::min<long long>(h.size(), n * D - off) * 2, hipMemcpyHostToDevice);
     hipMemcpy(q, h.data(), 1024 * D * 2, hipMemcpyHostToDevice);
-    hipMemset(xn, 0, (n + 512) * 4); hipMemset(cnt, 0, 4096);
+    hipMemset(xn, 0, (n + 512) * 4); hipMemset(cnt, 0, 16384);
     std::vector<float> t(1024, -1e30f); hipMemcpy(tau, t.data(), 4096, hipMemcpyHostToDevice);
     MfmaArgs a; a.rows = rows; a.xnorm = xn; a.n_rows = n; a.row_begin = 0; a.row_end = n; a.queries = q; a.n_queries = B;
     a.dim_pad = D; a.metric = CRAG_L2; a.tau = tau; a.sample = nullptr; a.sample_stride = 0; a.cand = cand; a.cnt = cnt;
@@ -29,5 +29,10 @@ int main(int argc, char** argv) {
     hipEventRecord(e0); for (int i = 0; i < 10; ++i) LAUNCH(a, 1, 256, nullptr); hipEventRecord(e1);
     hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     printf("B=%d  %.3f ms  %.1f GB/s  %.1f TFLOP/s  (%s)\n", B, ms, n * D * 2.0 / ms / 1e6, 2.0 * B * n * D / ms / 1e9, hipGetErrorString(hipGetLastError()));
+#ifdef Q2_PROFILE
+    uint32_t pc[4]; hipMemset(cnt, 0, 16384); LAUNCH(a, 1, 256, nullptr); hipDeviceSynchronize();
+    hipMemcpy(pc, cnt + 2000, 16, hipMemcpyDeviceToHost);
+    printf("per wave (100 MHz ticks): vmcnt wait %.1f  barrier %.1f  loop %.1f  (%u waves)\n", 1.0 * pc[0] / pc[3], 1.0 * pc[1] / pc[3], 1.0 * pc[2] / pc[3], pc[3]);
+#endif
     return 0;
 }

@@ -65,6 +65,19 @@ struct Workspace {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan timing (crag_set_profiling)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    uint32_t* pinned_status = nullptr;  // certificate read-back (pinned: a pageable D2H copy costs a staging round trip)
+    size_t pinned_status_cap = 0;
+    int ensure_pinned_status(size_t n) {
+        if (n <= pinned_status_cap) return 0;
+        if (pinned_status) (void)hipHostFree(pinned_status);
+        pinned_status = nullptr;
+        pinned_status_cap = 0;
+        const size_t want = n * 2 + 64;
+        hipError_t e = hipHostMalloc((void**)&pinned_status, want * sizeof(uint32_t), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(CRAG_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        pinned_status_cap = want;
+        return 0;
+    }
     int ensure_events() {
         for (auto& e : ev)
             if (!e && hipEventCreate(&e) != hipSuccess) return fail(CRAG_E_HIP, "hipEventCreate failed");
@@ -479,8 +492,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     bool patched = false;
 
     // ---- verify: every query must carry an exactness certificate ----
-    std::vector<uint32_t> hst((size_t)B);
-    HIPCHK(hipMemcpyAsync(hst.data(), status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
+    if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
+    uint32_t* hst = ws->pinned_status;
+    HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (prof) {
         float ms0 = 0.f, ms1 = 0.f;

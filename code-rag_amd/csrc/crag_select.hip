@@ -56,31 +56,118 @@ __global__ __launch_bounds__(256) void k_row_norms(const uint4* __restrict__ row
 }
 
 // ----------------------------------------------------------------------------------------
-// bitonic sort of P (power of two) 32-bit keys in LDS, ascending
-__device__ __forceinline__ void bitonic_sort_u32(uint32_t* s, int P) {
-    const int T = blockDim.x;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < (P >> 1); i += T) {
-                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const int b = a | j;
-                const bool up = (a & k) == 0;
-                const uint32_t x = s[a], y = s[b];
-                if ((x > y) == up) {
-                    s[a] = y;
-                    s[b] = x;
-                }
-            }
-            __syncthreads();
+// Block-wide selection (1024 threads) over n 32-bit keys read through key(i).  Returns, to every thread,
+// a key T with at least want + 1 keys <= T: the exact want-th smallest (0-based, want < n) unless the
+// histogram bin that holds it is crowded (> KTH_LIST keys, e.g. all keys equal), in which case T is that
+// bin's upper edge.  Selection, not sorting: min/max, a 4096-bin histogram of (key - min) >> shift, a
+// block scan to the bin that holds the wanted rank, then the exact rank inside that bin (sparse when the
+// wanted key sits in the tail of the score distribution, as it does here).
+// scratch: KTH_SCRATCH 32-bit words of LDS; the caller's LDS writes of the keys must be fenced by the caller.
+constexpr int KTH_BINS = 4096;
+constexpr int KTH_LIST = 1024;
+constexpr int KTH_SCRATCH = KTH_BINS + KTH_LIST + 48 + 4;
+template <typename KeyFn>
+__device__ __forceinline__ uint32_t block_select(KeyFn key, int n, uint32_t want, uint32_t* scratch) {
+    uint32_t* hist = scratch;              // [KTH_BINS]
+    uint32_t* list = hist + KTH_BINS;      // [KTH_LIST]
+    uint32_t* wsum = list + KTH_LIST;      // [48] wave totals, wave minima, wave maxima
+    uint32_t* ctl = wsum + 48;             // [4]: bin, rank inside the bin, list length, result
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t k = key(i);
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+    for (int i = tid; i < KTH_BINS; i += 1024) hist[i] = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off);
+        mn = o1 < mn ? o1 : mn;
+        mx = o2 > mx ? o2 : mx;
+    }
+    if (lane == 0) {
+        wsum[16 + wv] = mn;
+        wsum[32 + wv] = mx;
+    }
+    if (tid == 0) ctl[2] = 0;
+    __syncthreads();
+    mn = wsum[16];
+    mx = wsum[32];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+        mn = wsum[16 + w] < mn ? wsum[16 + w] : mn;
+        mx = wsum[32 + w] > mx ? wsum[32 + w] : mx;
+    }
+    const uint32_t range = mx - mn;
+    const int bits = range ? 32 - __builtin_clz(range) : 0;
+    const int shift = bits > 12 ? bits - 12 : 0;             // (key - mn) >> shift < 4096
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(key(i) - mn) >> shift], 1u);
+    __syncthreads();
+    // exclusive scan over the bins: thread t owns bins 4t .. 4t+3
+    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    const uint32_t mine = h0 + h1 + h2 + h3;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    const uint32_t exc = base + inc - mine;
+    const uint32_t M = want + 1;
+    if (exc < M && M <= exc + mine) {  // exactly one thread: the wanted key is in one of its bins
+        uint32_t e = exc;
+        int bsel = 4 * tid;
+        if (e + h0 < M) { e += h0; ++bsel;
+            if (e + h1 < M) { e += h1; ++bsel;
+                if (e + h2 < M) { e += h2; ++bsel; } } }
+        ctl[0] = (uint32_t)bsel;
+        ctl[1] = M - e - 1;  // rank of the wanted key inside bin bsel
+    }
+    __syncthreads();
+    const uint32_t bsel = ctl[0], rank = ctl[1];
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t k = key(i);
+        if (((k - mn) >> shift) == bsel) {
+            const uint32_t p = atomicAdd(&ctl[2], 1u);
+            if (p < KTH_LIST) list[p] = k;
         }
     }
+    __syncthreads();
+    const uint32_t L = ctl[2];
+    if (L > KTH_LIST) {  // crowded bin: its upper edge is a valid (looser) answer
+        if (tid == 0) {
+            const unsigned long long edge = (unsigned long long)mn + (((unsigned long long)bsel + 1) << shift) - 1;
+            ctl[3] = edge > mx ? mx : (uint32_t)edge;
+        }
+    } else if (tid < (int)L) {
+        const uint32_t k = list[tid];
+        uint32_t lt = 0, eq = 0;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint32_t o = list[j];
+            lt += o < k ? 1u : 0u;
+            eq += o == k ? 1u : 0u;
+        }
+        if (lt <= rank && rank < lt + eq) ctl[3] = k;  // duplicates write the same value
+    }
+    __syncthreads();
+    const uint32_t r = ctl[3];
+    __syncthreads();  // scratch may be reused at once
+    return r;
 }
 
-// per query: tau = score of the M-th smallest ordered key of a strided list (KthArgs in crag_common.h)
+// per query: tau = score of the M-th smallest ordered key of a strided list (KthArgs in crag_common.h);
+// any tau >= the true M-th smallest keeps the cascade exact (see block_select for when it is looser)
 __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* keys = (uint32_t*)smem;
+    uint32_t* keys = (uint32_t*)smem;                        // [CRAG_CAND_CAP]
+    uint32_t* scratch = keys + CRAG_CAND_CAP;                // [KTH_SCRATCH]
     const int q = blockIdx.x;
+    const int tid = threadIdx.x;
     const bool from_cand = a.cnt != nullptr;
     long long n;
     if (from_cand) {
@@ -90,18 +177,16 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
         n = a.qd[q].n_sample;
     }
     __syncthreads();
-    if (a.cnt_reset && threadIdx.x == 0) a.cnt_reset[q] = 0;
+    if (a.cnt_reset && tid == 0) a.cnt_reset[q] = 0;
     if (n < (long long)a.M || (!from_cand && n == (long long)a.M)) {
-        if (!from_cand && threadIdx.x == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
-        return;                                                            // from_cand: keep the looser tau
+        if (!from_cand && tid == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
+        return;                                                    // from_cand: keep the looser tau
     }
-    int P = 64;
-    while (P < n) P <<= 1;
     const uint32_t* __restrict__ src = a.src + (long long)q * a.q_stride + a.off0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = i < n ? src[(long long)i * a.e_stride] : 0xffffffffu;
+    for (int i = tid; i < (int)n; i += 1024) keys[i] = src[(long long)i * a.e_stride];
     __syncthreads();
-    bitonic_sort_u32(keys, P);
-    if (threadIdx.x == 0) a.tau[q] = crag_fkey_inv(keys[a.M - 1]);
+    const uint32_t t = block_select([&](int i) { return keys[i]; }, (int)n, (uint32_t)a.M - 1u, scratch);
+    if (tid == 0) a.tau[q] = crag_fkey_inv(t);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -125,23 +210,39 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* s, int P) {
     }
 }
 
-// canonical fp64 partial sum of lane j (elements d = j, j+8, ...), oracle/oracle.py order
-__device__ __forceinline__ double canon_lane(const void* row, const void* q, int dtype, int dim, int j, int metric,
-                                             long long row_off) {
+// canonical fp64 partial sum of lane j (elements d = j, j+8, ...), oracle/oracle.py order.  Eight elements
+// per step are loaded before the (sequential, order-defining) additions, so the loads overlap.
+template <int DT>
+__device__ __forceinline__ double canon_lane_t(const void* row, const void* q, int dim, int j, int metric, long long row_off) {
     double acc = 0.0;
-    for (int d = j; d < dim; d += 8) {
-        const double a = load_elem_f64(q, dtype, d);
-        const double b = load_elem_f64(row, dtype, row_off + d);
-        double p;
-        if (metric == CRAG_L2) {
-            const double t = __dsub_rn(a, b);
-            p = __dmul_rn(t, t);
-        } else {
-            p = __dmul_rn(a, b);
+    for (int d0 = j; d0 < dim; d0 += 64) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int d = d0 + 8 * u;
+            av[u] = d < dim ? load_elem_f64(q, DT, d) : 0.0;
+            bv[u] = d < dim ? load_elem_f64(row, DT, row_off + d) : 0.0;
         }
-        acc = __dadd_rn(acc, p);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (d0 + 8 * u < dim) {
+                double p;
+                if (metric == CRAG_L2) {
+                    const double t = __dsub_rn(av[u], bv[u]);
+                    p = __dmul_rn(t, t);
+                } else {
+                    p = __dmul_rn(av[u], bv[u]);
+                }
+                acc = __dadd_rn(acc, p);
+            }
+        }
     }
     return acc;
+}
+__device__ __forceinline__ double canon_lane(const void* row, const void* q, int dtype, int dim, int j, int metric,
+                                             long long row_off) {
+    return dtype == CRAG_F32 ? canon_lane_t<CRAG_F32>(row, q, dim, j, metric, row_off)
+                             : canon_lane_t<CRAG_BF16>(row, q, dim, j, metric, row_off);
 }
 
 __device__ __forceinline__ double combine8(double acc) {
@@ -152,11 +253,14 @@ __device__ __forceinline__ double combine8(double acc) {
     return acc;
 }
 
+constexpr int FIN_GATHER = 2048;  // candidates that survive the selection cut (m + 1 plus score ties), else sort all
 __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* skeys = (unsigned long long*)smem;                            // [CRAG_CAND_CAP]
     unsigned long long* ekeys = skeys + CRAG_CAND_CAP;                                // [CRAG_MAX_M]
     double* red = (double*)(ekeys + CRAG_MAX_M);                                      // [16]
+    uint32_t* sel_scratch = (uint32_t*)(red + 16);                                    // [KTH_SCRATCH]
+    uint32_t* sel_count = sel_scratch + KTH_SCRATCH;                                  // [1]
     const int q = blockIdx.x;
     const QueryDesc D = a.qd[q];
     const int tid = threadIdx.x;
@@ -164,14 +268,46 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     unsigned int status = CRAG_ST_OK;
     if (raw_cnt > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
     const int c = raw_cnt < CRAG_CAND_CAP ? (int)raw_cnt : CRAG_CAND_CAP;
-    int P = 64;
-    while (P < c) P <<= 1;
+    const int m = c < a.M ? c : a.M;  // candidates re-scored exactly
     const unsigned long long* __restrict__ cq = a.cand + (long long)q * CRAG_CAND_CAP;
-    for (int i = tid; i < P; i += blockDim.x) skeys[i] = i < c ? cq[i] : ~0ull;
+    // skeys[0 .. m] = the m + 1 smallest candidates in (score, row) order (skeys[m], the best candidate NOT
+    // re-scored, bounds the certificate).  Small buffers are sorted whole; big ones are first cut down to the
+    // candidates whose score is <= the (m + 1)-th smallest score (selection), and only those are sorted.
+    int c_sorted = c;
+    if (c > 256) {
+        for (int i = tid; i < c; i += 1024) skeys[i] = cq[i];
+        __syncthreads();
+        const uint32_t want = (uint32_t)(m < c ? m : c - 1);
+        const uint32_t t = block_select([&](int i) { return (uint32_t)(skeys[i] >> 32); }, c, want, sel_scratch);
+        // compact in place is not possible without a second buffer: gather into the tail region of skeys
+        unsigned long long* gathered = skeys + CRAG_CAND_CAP - FIN_GATHER;
+        if (tid == 0) *sel_count = 0;
+        __syncthreads();
+        if (c <= CRAG_CAND_CAP - FIN_GATHER) {
+            for (int i = tid; i < c; i += 1024) {
+                const unsigned long long k = skeys[i];
+                if ((uint32_t)(k >> 32) <= t) {
+                    const uint32_t p = atomicAdd(sel_count, 1u);
+                    if (p < FIN_GATHER) gathered[p] = k;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t L = *sel_count;
+        __syncthreads();
+        if (c <= CRAG_CAND_CAP - FIN_GATHER && L <= FIN_GATHER) {  // L >= want + 1 by construction
+            for (int i = tid; i < (int)L; i += 1024) skeys[i] = gathered[i];  // FIN_GATHER <= CAP / 2: no overlap
+            c_sorted = (int)L;
+            __syncthreads();
+        }
+    } else {
+        for (int i = tid; i < c; i += 1024) skeys[i] = cq[i];
+    }
+    int P = 64;
+    while (P < c_sorted) P <<= 1;
+    for (int i = c_sorted + tid; i < P; i += 1024) skeys[i] = ~0ull;
     __syncthreads();
     bitonic_sort_u64(skeys, P);
-
-    const int m = c < a.M ? c : a.M;  // candidates re-scored exactly
     const size_t esz = a.dtype == CRAG_F32 ? 4 : 2;
     const void* qv = (const char*)a.queries + (size_t)q * a.dim_pad * esz;
 
@@ -442,13 +578,19 @@ int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n,
 }
 
 int crag_launch_kth(const KthArgs& a, hipStream_t s) {
-    const size_t lds = sizeof(uint32_t) * CRAG_CAND_CAP;
+    const size_t lds = sizeof(uint32_t) * (CRAG_CAND_CAP + KTH_SCRATCH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_kth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k_kth, dim3(a.B), dim3(1024), lds, s, a);
     return (int)hipGetLastError();
 }
 
 int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s) {
-    const size_t lds = sizeof(unsigned long long) * (CRAG_CAND_CAP + CRAG_MAX_M) + sizeof(double) * 16;
+    const size_t lds = sizeof(unsigned long long) * (CRAG_CAND_CAP + CRAG_MAX_M) + sizeof(double) * 16 +
+                       sizeof(uint32_t) * (KTH_SCRATCH + 4);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

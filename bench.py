@@ -146,12 +146,13 @@ def main():
 
     # ---- roofline of the dominant kernel (filter-pass scan) ----------------------------------
     scan_ms = prof["filter_scan_ms"] / max(prof["searches"], 1)
-    alg_bytes = n * d * 2 + n * 4          # rows once + |x|^2 column, per launch
-    flops = 2.0 * B * n * d
+    scan_rows = prof["filter_scan_rows"] / max(prof["searches"], 1)   # rows minus the level-1 prefix
+    alg_bytes = int(scan_rows * (d * 2 + 4))  # rows once + |x|^2 column, per launch
+    flops = 2.0 * B * scan_rows * d
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
     roofline = {
-        "kernel": ("k_scan_qreg2" if B > 128 else "k_scan_qreg" if B >= 9 else "k_scan_gemv") + " (filter pass over all rows)",
+        "kernel": ("k_scan_qreg2" if B > 128 else "k_scan_qreg" if B >= 9 else "k_scan_gemv") + " (full filter pass: rows behind the level-1 prefix)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,
@@ -160,6 +161,7 @@ def main():
         "traffic": pmc_traffic(n, d, B),
         "kernel_ms": round(scan_ms, 4),
         "algorithmic_bytes": alg_bytes,
+        "rows_scanned": int(scan_rows),
         "mfma_tflops": round(flops / (scan_ms * 1e-3) / 1e12, 2) if scan_ms > 0 else 0.0,
         "mfma_frac": round(flops / (scan_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if scan_ms > 0 else 0.0,
     }
@@ -220,8 +222,9 @@ def extra_regimes(col, q, n, d, torch):
         col.set_profiling(False)
         prof = col.profile(reset=True)
         ms = prof["filter_scan_ms"] / max(prof["searches"], 1)
-        gbs = (n * d * 2 + n * 4) / (ms * 1e-3) / 1e9
-        tf = 2.0 * B * n * d / (ms * 1e-3) / 1e12
+        sr = prof["filter_scan_rows"] / max(prof["searches"], 1)
+        gbs = sr * (d * 2 + 4) / (ms * 1e-3) / 1e9
+        tf = 2.0 * B * sr * d / (ms * 1e-3) / 1e12
         out.append({"regime": name, "queries_per_s": round(B * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 4),
                     "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                     "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
@@ -259,7 +262,7 @@ def config_regimes(ch, torch, np, dev):
     dt = time.perf_counter() - t0
     pr = c2.profile(reset=True)
     ms = pr["filter_scan_ms"] / max(pr["searches"], 1)
-    gbs = (n2 * d2 * 4 + n2 * 4) / (ms * 1e-3) / 1e9
+    gbs = pr["filter_scan_rows"] / max(pr["searches"], 1) * (d2 * 4 + 4) / (ms * 1e-3) / 1e9
     out.append({"regime": "configs[1]: 1M x 384 fp32, batch-1 top-10 GEMV", "queries_per_s": round(50 / dt, 2),
                 "ms_per_batch": round(dt / 50 * 1e3, 4), "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1),
                 "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})

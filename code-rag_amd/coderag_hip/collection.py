@@ -274,9 +274,10 @@ class GpuCollection:
         check(self._lib.crag_set_profiling(self._h, int(bool(on))))
 
     def profile(self, reset: bool = False) -> dict:
-        a = np.zeros(3, np.float64)
+        a = np.zeros(4, np.float64)
         check(self._lib.crag_get_profile(self._h, a.ctypes.data, int(reset)))
-        return {"sample_scan_ms": float(a[0]), "filter_scan_ms": float(a[1]), "searches": int(a[2])}
+        return {"sample_scan_ms": float(a[0]), "filter_scan_ms": float(a[1]), "searches": int(a[2]),
+                "filter_scan_rows": float(a[3])}
 
     def set_path(self, path: str):
         check(self._lib.crag_set_path(self._h, {"auto": 0, "gemv": 1, "mfma": 2}[path]))

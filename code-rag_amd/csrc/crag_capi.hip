@@ -169,7 +169,7 @@ struct crag_index {
     int n_cus = 256;
     int profiling = 0;
     std::mutex prof_mu;
-    double prof[4] = {0, 0, 0, 0};  // sample-scan ms, filter-scan ms, searches timed, unused
+    double prof[4] = {0, 0, 0, 0};  // sample-scan ms, filter-scan ms, searches timed, rows the filter-pass launches scanned
     std::atomic<long long> stats[7];
     crag_index() {
         for (auto& s : stats) s = 0;
@@ -285,6 +285,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     const int path = h0->force_path;
     P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 9));
 
+    const bool mfma_v1 = P.mfma && !crag_qreg_supported(h0->dim_pad);  // k_scan_mfma always scans from row 0
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
     std::vector<GroupDesc> gd;
@@ -300,7 +301,13 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         d.n_mid = level1_rows(h->n_rows, d.n_sample, P.M);
         d.id_base = h->id_base;
         d.max_xnorm = h->max_xnorm;
-        d.pad = 0;
+        // keep the level-1 candidates and let the full scan start at n_mid when both levels fit the buffer
+        // with a 2x margin (expected survivors: M n1/n0 + M N/n1); otherwise level 1 only sets tau
+        d.keep_mid = 0;
+        if (d.n_mid > d.n_sample && d.n_mid < d.n_rows && d.n_mid % 128 == 0 && !mfma_v1) {
+            const double est = (double)P.M * ((double)d.n_mid / (double)d.n_sample + (double)d.n_rows / (double)d.n_mid);
+            d.keep_mid = est <= CRAG_CAND_CAP / 2 ? 1 : 0;
+        }
         P.sample_stride = std::max<long long>(P.sample_stride, d.n_sample);
         P.need_mid = P.need_mid || d.n_mid > d.n_sample;
     }
@@ -320,6 +327,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             g.n_mid = qd[(size_t)b].n_mid;
             g.q_first = b;
             g.nq = e - b;
+            g.full_from = qd[(size_t)b].keep_mid ? g.n_mid : 0;  // same collection => same decision for the group
             max_nq = std::max(max_nq, g.nq);
             gd.push_back(g);
             b = e;
@@ -331,7 +339,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             auto rows_of = [&](const GroupDesc& g) {
                 if (pass == 0) return g.n_sample;
                 if (pass == 1) return g.n_mid > g.n_sample ? g.n_mid : 0LL;  // level 1 only where it exists
-                return g.n_rows;
+                return g.n_rows - g.full_from;
             };
             long long total_st = 0;
             for (auto& g : gd) total_st += (rows_of(g) + RT - 1) / RT;
@@ -415,6 +423,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     auto scan = [&](int pass) -> int {
         if (P.mfma) {
             ma.row_end = pass == 0 ? qd[0].n_sample : (pass == 1 ? qd[0].n_mid : h0->n_rows);
+            ma.row_begin = pass == 2 && qd[0].keep_mid ? qd[0].n_mid : 0;
             if (!qreg) return crag_launch_scan_mfma(ma, pass ? 1 : 0, st);
             return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
                                       : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
@@ -504,6 +513,10 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         h0->prof[0] += ms0;
         h0->prof[1] += ms1;
         h0->prof[2] += 1.0;
+        double scanned = 0.0;
+        if (P.mfma) scanned = (double)(h0->n_rows - (qd[0].keep_mid ? qd[0].n_mid : 0));
+        for (const auto& g : gd) scanned += (double)(g.n_rows - g.full_from);
+        h0->prof[3] += scanned;
     }
     h0->stats[0]++;
     h0->stats[1] += B;
@@ -1040,11 +1053,11 @@ int crag_set_profiling(crag_index* h, int on) {
     return 0;
 }
 
-int crag_get_profile(crag_index* h, double* out3, int reset) {
-    if (!h || !out3) return fail(CRAG_E_INVALID, "crag_get_profile: bad arguments");
+int crag_get_profile(crag_index* h, double* out4, int reset) {
+    if (!h || !out4) return fail(CRAG_E_INVALID, "crag_get_profile: bad arguments");
     std::lock_guard<std::mutex> lk(h->prof_mu);
-    for (int i = 0; i < 3; ++i) {
-        out3[i] = h->prof[i];
+    for (int i = 0; i < 4; ++i) {
+        out4[i] = h->prof[i];
         if (reset) h->prof[i] = 0.0;
     }
     return 0;

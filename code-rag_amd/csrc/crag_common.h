@@ -38,6 +38,7 @@ struct GroupDesc {
     int q_first, nq;
     int blk_first[3];  // per pass: 0 dense sample, 1 level-1 filter, 2 full filter
     int n_blk[3];
+    long long full_from;  // pass 2 scans rows [full_from, n_rows): n_mid when the level-1 candidates are kept, else 0
 };
 
 // Everything the per-query kernels need (one per query of the batch).
@@ -51,7 +52,7 @@ struct QueryDesc {
     long long n_mid;
     long long id_base;
     float max_xnorm;
-    int pad;
+    int keep_mid;  // level-1 candidates stay in the buffer and the full scan starts at n_mid (no double scan)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -96,7 +97,7 @@ bool crag_gemv_supported(int dtype, int chunks);
 struct MfmaArgs {
     const void* rows;
     const float* xnorm;
-    long long n_rows;   // rows scanned by this launch: [row_begin, row_end)
+    long long n_rows;   // rows scanned by this launch: [row_begin, row_end); row_begin is a multiple of 32
     long long row_begin, row_end;
     const void* queries;  // [Bpad][dim_pad] bf16
     int n_queries;        // real queries

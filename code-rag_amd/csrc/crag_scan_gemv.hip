@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     const float my_tau = mode ? tau[qg] : 0.f;
     const uint4* __restrict__ rows = (const uint4*)gp->rows;
 
-    for (long long t = w; t < n_st; t += n_waves) {
+    // the full pass skips the rows level 1 already filtered into the buffer (full_from is a multiple of 128)
+    const long long t_first = pass == 2 ? gp->full_from / RT : 0;
+    for (long long t = t_first + w; t < n_st; t += n_waves) {
         const long long row0 = t * RT;
         const uint4* __restrict__ base = rows + row0 * C;
         long long rel_max_ll = (R - row0) * C - 1;

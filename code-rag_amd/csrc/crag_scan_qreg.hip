@@ -57,7 +57,7 @@ constexpr int QR_XN_BYTES = 256;  // per wave and stage: |x|^2 of the tile's row
 
 template <int KS, int MODE>
 __global__ __launch_bounds__(64 * QR_WAVES, 1) void k_scan_qreg(const unsigned short* __restrict__ rows,
-                                                      const float* __restrict__ xnorm, long long row_end,
+                                                      const float* __restrict__ xnorm, long long row_begin, long long row_end,
                                                       const unsigned short* __restrict__ queries, int n_queries,
                                                       int nqg, int metric, const float* __restrict__ tau,
                                                       uint32_t* __restrict__ sample, long long sample_stride,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * QR_WAVES, 1) void k_scan_qreg(const unsigned s
     const int n_streams = (int)(gridDim.x >> 3) / nqg;
     const long long n_tiles = (row_end + QR_TM - 1) / QR_TM;
     const long long t_step = (long long)n_streams * 8;
-    long long t = (long long)stream * 8 + xcd;
+    long long t = row_begin / QR_TM + (long long)stream * 8 + xcd;  // row_begin: a multiple of the tile height
 
     const int q_base = qg * QR_QPB + wave * QR_QPW;
     const bool wave_active = q_base < n_queries;  // wave-uniform
@@ -275,11 +275,11 @@ int launch_ks(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
     }
     if (mode == 0)
         hipLaunchKernelGGL((k_scan_qreg<KS, 0>), dim3(grid), dim3(64 * QR_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
-                           a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
+                           a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
                            a.sample_stride, a.cand, a.cnt);
     else
         hipLaunchKernelGGL((k_scan_qreg<KS, 1>), dim3(grid), dim3(64 * QR_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
-                           a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
+                           a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
                            a.sample_stride, a.cand, a.cnt);
     return (int)hipGetLastError();
 }
@@ -290,12 +290,13 @@ bool crag_qreg_supported(int dim_pad) { return dim_pad == 256 || dim_pad == 384 
 
 // sample layout of this kernel: sample[row * sample_stride + query]  (row-major)
 int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
-    if (a.row_end <= 0 || a.n_queries <= 0) return 0;
+    if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
+    if (a.row_begin % QR_TM) return -1;
     const int nqg = (a.n_queries + QR_QPB - 1) / QR_QPB;
     if (nqg > 32) return -1;
     int streams = (n_cus / 8) / nqg;  // row-tile streams per XCD
     if (streams < 1) streams = 1;
-    const long long n_tiles = (a.row_end + QR_TM - 1) / QR_TM;
+    const long long n_tiles = (a.row_end - a.row_begin + QR_TM - 1) / QR_TM;
     while (streams > 1 && (long long)streams * 8 > n_tiles) --streams;
     const int grid = 8 * streams * nqg;
     switch (a.dim_pad) {

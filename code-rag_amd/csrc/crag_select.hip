@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
         n = a.qd[q].n_sample;
     }
     __syncthreads();
-    if (a.cnt_reset && tid == 0) a.cnt_reset[q] = 0;
+    if (a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[q] = 0;  // kept: the full scan appends behind them
     if (n < (long long)a.M || (!from_cand && n == (long long)a.M)) {
         if (!from_cand && tid == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
         return;                                                    // from_cand: keep the looser tau

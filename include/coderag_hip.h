@@ -168,8 +168,9 @@ int crag_set_path(crag_index* h, int path);
 /*
  * Kernel timing for bench.py's roofline line: when on, every search brackets its two scan
  * launches with HIP events on the stream they are launched on.  crag_get_profile returns
- * [0] total ms of sample-pass scans, [1] total ms of filter-pass scans (the HBM/MFMA-bound
- * kernel), [2] searches timed.
+ * [0] total ms of the sample + level-1 passes, [1] total ms of the filter-pass scans (the
+ * HBM/MFMA-bound kernel), [2] searches timed, [3] total rows those filter-pass launches scanned
+ * (a collection's rows minus the level-1 prefix whose candidates were kept).
  */
 int crag_set_profiling(crag_index* h, int on);
 /*
@@ -179,7 +180,7 @@ int crag_set_profiling(crag_index* h, int on);
  */
 int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int path, float* out_scores_dev,
                             void* stream);
-int crag_get_profile(crag_index* h, double* out3, int reset);
+int crag_get_profile(crag_index* h, double* out4, int reset);
 
 #ifdef __cplusplus
 }

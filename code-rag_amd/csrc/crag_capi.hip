@@ -61,7 +61,7 @@ struct DevBuf {
 struct Workspace {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf q, desc, tau, cntst, sample, cand, entries, qhash, out, keys, misc;
+    DevBuf q, desc, tau, cntst, segcnt, sample, cand, entries, qhash, out, keys, misc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan timing (crag_set_profiling)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -385,6 +385,20 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     uint32_t* sample = (uint32_t*)ws->sample.p;
     unsigned long long* cand = (unsigned long long*)ws->cand.p;
     HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)B, st));
+    // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics)
+    const bool segmented = qreg && B > 128;
+    const int n_seg = segmented ? crag_qreg2_segments(B, h0->n_cus) : 0;
+    // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64): the COUNT must stay <= CAP
+    const int seg_cap = segmented ? std::max(64, 2 * CRAG_CAND_CAP / n_seg) : 0;
+    const long long cand_stride = segmented ? (long long)n_seg * seg_cap : (long long)CRAG_CAND_CAP;
+    if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * (size_t)cand_stride))) return rc;
+    cand = (unsigned long long*)ws->cand.p;
+    uint32_t* segcnt = nullptr;
+    if (segmented) {
+        if ((rc = ws->segcnt.ensure(sizeof(uint32_t) * (size_t)B * (size_t)n_seg))) return rc;
+        segcnt = (uint32_t*)ws->segcnt.p;
+        HIPCHK(hipMemsetAsync(segcnt, 0, sizeof(uint32_t) * (size_t)B * (size_t)n_seg, st));
+    }
 
     // ---- passes ----
     const bool prof = h0->profiling != 0;
@@ -404,6 +418,10 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         ma.sample_stride = qreg ? bpad : P.sample_stride;  // qreg: row-major sample [row][bpad]
         ma.cand = cand;
         ma.cnt = cnt;
+        ma.segcnt = segcnt;
+        ma.n_seg = n_seg;
+        ma.seg_cap = seg_cap;
+        ma.cand_stride = cand_stride;
         ma.row_begin = 0;
         h0->stats[5]++;
     } else {
@@ -450,6 +468,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         k.B = B;
         k.M = P.M;
         k.tau = tau;
+        k.segcnt = nullptr;
+        k.n_seg = 0;
+        k.seg_cap = 0;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
     }
     // level 1: filtered scan of the first n1 rows -> tau1 (tightens tau0; never loosens it)
@@ -457,7 +478,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         if (scan(1)) return fail(CRAG_E_HIP, "level-1 scan launch failed");
         KthArgs k;
         k.src = (const uint32_t*)cand;
-        k.q_stride = 2LL * CRAG_CAND_CAP;
+        k.q_stride = 2LL * cand_stride;
         k.e_stride = 2;
         k.off0 = 1;  // high word of the 64-bit key = ordered score
         k.qd = qd_dev;
@@ -466,6 +487,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         k.B = B;
         k.M = P.M;
         k.tau = tau;
+        k.segcnt = segcnt;
+        k.n_seg = n_seg;
+        k.seg_cap = seg_cap;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 1) launch failed");
     }
     if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
@@ -491,6 +515,10 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     f.qhash_off = (const int*)qhoff_dev;
     f.entries = entries_dev;
     f.status = status;
+    f.segcnt = segcnt;
+    f.n_seg = n_seg;
+    f.seg_cap = seg_cap;
+    f.cand_stride = cand_stride;
     if ((rc = crag_launch_finalize(f, st))) return fail(CRAG_E_HIP, "finalize launch failed");
     auto merge = [&]() -> int {
         if (!mo) return 0;
@@ -572,6 +600,10 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         g.cnt = cnt + b;
         g.tau = (const float*)ws->tau.p + b;
         g.trusted = 1;
+        g.segcnt = nullptr;  // the fallback's gather fills the flat buffer
+        g.n_seg = 0;
+        g.seg_cap = 0;
+        g.cand_stride = CRAG_CAND_CAP;
         g.qhash_off = qhoff_dev ? (const int*)qhoff_dev + b : nullptr;
         g.entries = entries_dev + (size_t)b * P.kc;
         g.status = status + b;

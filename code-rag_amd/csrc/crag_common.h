@@ -108,6 +108,12 @@ struct MfmaArgs {
     long long sample_stride;
     unsigned long long* cand;
     uint32_t* cnt;
+    // crag_launch_scan_qreg2 only: SEGMENTED candidate buffers.  A query's cand_stride slots are cut into
+    // n_seg segments of seg_cap, two per workgroup that scans for the query; a lane appends to its own segment
+    // with a private counter (segcnt[q * n_seg + seg], loaded at kernel start, stored at its end): no atomics.
+    uint32_t* segcnt;
+    int n_seg, seg_cap;
+    long long cand_stride;  // slots per query = n_seg * seg_cap (may exceed CRAG_CAND_CAP; the COUNT may not)
 };
 int crag_launch_scan_mfma(const MfmaArgs& a, int mode, hipStream_t s);
 // query-stationary MFMA scan (dim_pad in {256,384,512,768}); its sample is ROW-major [row][stride]
@@ -115,6 +121,8 @@ bool crag_qreg_supported(int dim_pad);
 int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // same contract, 256 queries per workgroup (two 32-query blocks per wave): the choice for B > 128
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)
+int crag_qreg2_segments(int n_queries, int n_cus);
 
 
 int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n, float* xnorm, float* max_out,
@@ -132,6 +140,8 @@ struct KthArgs {
     uint32_t* cnt_reset;
     int B, M;
     float* tau;
+    uint32_t* segcnt;  // segmented candidate buffer (see MfmaArgs) when n_seg > 0; then cnt / cnt_reset are unused
+    int n_seg, seg_cap;
 };
 int crag_launch_kth(const KthArgs& a, hipStream_t s);
 struct FinalizeArgs {
@@ -147,6 +157,9 @@ struct FinalizeArgs {
     const int* qhash_off;             // [B+1], may be null
     CragEntry* entries;               // [B][kc]
     uint32_t* status;                 // [B]
+    const uint32_t* segcnt;           // segmented candidate buffer (see MfmaArgs) when n_seg > 0; then cnt is unused
+    int n_seg, seg_cap;
+    long long cand_stride;            // slots per query in cand (CRAG_CAND_CAP when flat)
 };
 int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s);
 int crag_launch_merge_rerank(const CragEntry* entries, int G, int B, int kc, int top_k, double symbol_boost,

@@ -52,27 +52,19 @@ struct Qreg2Dma {
 #endif
 #include Q2_KLOOP_INC
 
-// slow path of the filter for one query block: this lane's query has at least one passing row
+// slow path of the filter for one query block: this lane's query has at least one passing row.  The lane
+// appends to ITS segment of the query's candidate buffer (two segments per workgroup that scans for the
+// query -- a query sits on lanes fr and fr + 32, which hold different rows of the tile -- MfmaArgs in
+// crag_common.h) with a private counter: no atomic, no round trip to memory.
 __device__ __forceinline__ void q2_append(const f32x16_t& acc, const f32x16_t& xs, float c, float tq, unsigned mb,
-                                          unsigned row_end, int q, unsigned long long* __restrict__ cand,
-                                          uint32_t* __restrict__ cnt) {
-    int npass = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
-        npass += (fmaf(c, acc[r], xs[r]) <= tq && m < row_end) ? 1 : 0;
-    }
-    if (!npass) return;
-    asm volatile("" : "+v"(q));  // address arithmetic stays on this rare path (not hoisted into live registers)
-    // one returning atomic per lane (= per query) for all of its passing rows
-    unsigned pos = atomicAdd(&cnt[q], (unsigned)npass);
-    unsigned long long* cq = cand + (long long)q * CRAG_CAND_CAP;
+                                          unsigned row_end, unsigned long long* __restrict__ cq, unsigned seg_cap,
+                                          unsigned& pos) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned m = mb + 8 * (r >> 2) + (r & 3);
         const float s = fmaf(c, acc[r], xs[r]);
         if (s <= tq && m < row_end) {
-            if (pos < CRAG_CAND_CAP) cq[pos] = ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)m;
+            if (pos < seg_cap) cq[pos] = ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)m;
             ++pos;
         }
     }
@@ -85,7 +77,7 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                                                                  int nqg, int metric, const float* __restrict__ tau,
                                                                  uint32_t* __restrict__ sample, long long sample_stride,
                                                                  unsigned long long* __restrict__ cand,
-                                                                 uint32_t* __restrict__ cnt) {
+                                                                 uint32_t* __restrict__ segcnt, int n_seg, int seg_cap, long long cand_stride) {
     constexpr int C = KS * 2;                  // 16-byte chunks per row
     constexpr int D = KS * 16;                 // elements per row
     constexpr int ROWB = C * 16;               // bytes per row (a multiple of 256)
@@ -123,6 +115,11 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
     if (MODE == 1 && ok0) tq0 = tau[q0];
     if (MODE == 1 && ok1) tq1 = tau[q1];
+    // this workgroup's segment of its queries' candidate buffers, and the lane's two private counters
+    const int seg = (stream * 8 + xcd) * 2 + fh;  // < n_seg
+    unsigned pos0 = 0, pos1 = 0;
+    if (MODE == 1 && ok0) pos0 = segcnt[(long long)q0 * n_seg + seg];
+    if (MODE == 1 && ok1) pos1 = segcnt[(long long)q1 * n_seg + seg];
 
     // LDS-DMA of one tile: 1-KiB pieces of the lane-linear image; linear 16-byte position P holds global
     // chunk (row P / C, chunk (P % C) ^ (row & 15)).  A wave takes pieces wave + WAVES*i of each 16-row half
@@ -236,8 +233,16 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                         }
                     }
                 } else {
-                    if (hit0) q2_append(acc0, xs, e.c, tq0, mb, re, q0, cand, cnt);
-                    if (hit1) q2_append(acc1, xs, e.c, tq1, mb, re, q1, cand, cnt);
+                    if (hit0 || hit1) {
+                        int qa = q0;
+                        asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path (not hoisted)
+                        unsigned long long* cq = cand + (long long)qa * cand_stride + (long long)seg * seg_cap;
+                        if (hit0) q2_append(acc0, xs, e.c, tq0, mb, re, cq, (unsigned)seg_cap, pos0);
+                        if (hit1) q2_append(acc1, xs, e.c, tq1, mb, re, cq + 32ll * cand_stride, (unsigned)seg_cap, pos1);
+                    }
+                    // vmcnt counts these stores too and they may retire out of order with the DMA loads, so the
+                    // counted wait below would no longer prove that the next tile has landed: drain everything
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
             }
         }
@@ -262,12 +267,17 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
 #endif
         cur = cur + 1 == Q2_NSTAGE ? 0 : cur + 1;
     }
+    if (MODE == 1 && wave_active) {
+        if (ok0) segcnt[(long long)q0 * n_seg + seg] = pos0;
+        if (ok1) segcnt[(long long)q1 * n_seg + seg] = pos1;
+    }
 #ifdef Q2_PROFILE
     if (lane == 0) {
-        atomicAdd(&cnt[2000], (unsigned)prof_wait);
-        atomicAdd(&cnt[2001], (unsigned)prof_bar);
-        atomicAdd(&cnt[2002], (unsigned)(__builtin_readcyclecounter() - prof_t0));
-        atomicAdd(&cnt[2003], 1u);
+        uint32_t* pc = segcnt + Q2_PROFILE;  // tools/qreg_bench.hip: counters behind the segment counters
+        atomicAdd(&pc[0], (unsigned)prof_wait);
+        atomicAdd(&pc[1], (unsigned)prof_bar);
+        atomicAdd(&pc[2], (unsigned)(__builtin_readcyclecounter() - prof_t0));
+        atomicAdd(&pc[3], 1u);
     }
 #endif
 }
@@ -286,19 +296,28 @@ int launch_ks(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
     if (mode == 0)
         hipLaunchKernelGGL((k_scan_qreg2<KS, 0>), dim3(grid), dim3(64 * Q2_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
                            a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
-                           a.sample_stride, a.cand, a.cnt);
+                           a.sample_stride, a.cand, a.segcnt, a.n_seg, a.seg_cap, a.cand_stride);
     else
         hipLaunchKernelGGL((k_scan_qreg2<KS, 1>), dim3(grid), dim3(64 * Q2_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
                            a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
-                           a.sample_stride, a.cand, a.cnt);
+                           a.sample_stride, a.cand, a.segcnt, a.n_seg, a.seg_cap, a.cand_stride);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
+int crag_qreg2_segments(int n_queries, int n_cus) {
+    const int nqg = (n_queries + Q2_QPB - 1) / Q2_QPB;
+    const int streams = (n_cus / 8) / nqg;
+    return 2 * 8 * (streams < 1 ? 1 : streams);  // two per workgroup: one per half-wave (row half fh)
+}
+
 // sample layout of this kernel: sample[row * sample_stride + query]  (row-major), as crag_launch_scan_qreg
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
+    if (mode == 1 && (a.n_seg != crag_qreg2_segments(a.n_queries, n_cus) || a.seg_cap < 1 ||
+                      (long long)a.n_seg * a.seg_cap != a.cand_stride || !a.segcnt))
+        return -1;
     if (a.row_begin % Q2_TM) return -1;
     const int nqg = (a.n_queries + Q2_QPB - 1) / Q2_QPB;
     if (nqg > 32) return -1;

@@ -160,6 +160,40 @@ __device__ __forceinline__ uint32_t block_select(KeyFn key, int n, uint32_t want
     return r;
 }
 
+// Segmented candidate buffer (MfmaArgs in crag_common.h): exclusive prefix of the per-segment counts of one
+// query into segoff[0 .. n_seg] (LDS), returns the total; *overflow if a segment ran over.  n_seg <= 1024.
+__device__ __forceinline__ int block_seg_offsets(const uint32_t* __restrict__ segcnt_q, int n_seg, int seg_cap,
+                                                 uint32_t* segoff, uint32_t* wsum, bool* overflow) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t c = tid < n_seg ? segcnt_q[tid] : 0u;
+    const bool ov = c > (uint32_t)seg_cap;
+    c = ov ? (uint32_t)seg_cap : c;
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    const int any_ov = __syncthreads_or(ov ? 1 : 0);
+    uint32_t base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    if (tid < n_seg) segoff[tid] = base + inc - c;
+    if (tid == n_seg - 1) segoff[n_seg] = base + inc;
+    __syncthreads();
+    *overflow = any_ov != 0;
+    return (int)segoff[n_seg];
+}
+// slot of the i-th gathered candidate: segment by binary search in segoff, then its position inside
+__device__ __forceinline__ int seg_slot(const uint32_t* segoff, int n_seg, int seg_cap, int i) {
+    int lo = 0, hi = n_seg;  // segoff[lo] <= i < segoff[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (segoff[mid] <= (uint32_t)i) lo = mid; else hi = mid;
+    }
+    return lo * seg_cap + (i - (int)segoff[lo]);
+}
+
 // per query: tau = score of the M-th smallest ordered key of a strided list (KthArgs in crag_common.h);
 // any tau >= the true M-th smallest keeps the cascade exact (see block_select for when it is looser)
 __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
@@ -168,22 +202,31 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     uint32_t* scratch = keys + CRAG_CAND_CAP;                // [KTH_SCRATCH]
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const bool from_cand = a.cnt != nullptr;
+    const bool seg = a.n_seg > 0;
+    const bool from_cand = seg || a.cnt != nullptr;
     long long n;
-    if (from_cand) {
+    if (seg) {
+        bool ov;  // an overflowed segment still holds seg_cap rows <= the old tau
+        n = block_seg_offsets(a.segcnt + (long long)q * a.n_seg, a.n_seg, a.seg_cap, scratch, scratch + KTH_BINS + KTH_LIST, &ov);
+        if (n > CRAG_CAND_CAP) n = CRAG_CAND_CAP;  // the first CAP gathered rows are all <= the old tau
+        if (!a.qd[q].keep_mid && tid < a.n_seg) a.segcnt[(long long)q * a.n_seg + tid] = 0;
+    } else if (from_cand) {
         const unsigned int c = a.cnt[q];
         n = c < CRAG_CAND_CAP ? c : CRAG_CAND_CAP;  // an overflowed buffer still holds CAP rows <= the old tau
     } else {
         n = a.qd[q].n_sample;
     }
     __syncthreads();
-    if (a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[q] = 0;  // kept: the full scan appends behind them
+    if (!seg && a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[q] = 0;  // kept: the full scan appends behind them
     if (n < (long long)a.M || (!from_cand && n == (long long)a.M)) {
         if (!from_cand && tid == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
         return;                                                    // from_cand: keep the looser tau
     }
     const uint32_t* __restrict__ src = a.src + (long long)q * a.q_stride + a.off0;
-    for (int i = tid; i < (int)n; i += 1024) keys[i] = src[(long long)i * a.e_stride];
+    for (int i = tid; i < (int)n; i += 1024) {
+        const int e = seg ? seg_slot(scratch, a.n_seg, a.seg_cap, i) : i;
+        keys[i] = src[(long long)e * a.e_stride];
+    }
     __syncthreads();
     const uint32_t t = block_select([&](int i) { return keys[i]; }, (int)n, (uint32_t)a.M - 1u, scratch);
     if (tid == 0) a.tau[q] = crag_fkey_inv(t);
@@ -260,22 +303,33 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     unsigned long long* ekeys = skeys + CRAG_CAND_CAP;                                // [CRAG_MAX_M]
     double* red = (double*)(ekeys + CRAG_MAX_M);                                      // [16]
     uint32_t* sel_scratch = (uint32_t*)(red + 16);                                    // [KTH_SCRATCH]
-    uint32_t* sel_count = sel_scratch + KTH_SCRATCH;                                  // [1]
+    uint32_t* sel_count = sel_scratch + KTH_SCRATCH;                                  // [4]
+    uint32_t* seg_off = sel_count + 4;                                                // [1024 + 1] segment offsets
     const int q = blockIdx.x;
     const QueryDesc D = a.qd[q];
     const int tid = threadIdx.x;
-    const unsigned int raw_cnt = a.cnt[q];
     unsigned int status = CRAG_ST_OK;
-    if (raw_cnt > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
-    const int c = raw_cnt < CRAG_CAND_CAP ? (int)raw_cnt : CRAG_CAND_CAP;
+    const bool seg = a.n_seg > 0;
+    int c;
+    if (seg) {
+        bool ov;
+        c = block_seg_offsets(a.segcnt + (long long)q * a.n_seg, a.n_seg, a.seg_cap, seg_off, sel_scratch, &ov);
+        if (ov || c > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
+        if (c > CRAG_CAND_CAP) c = CRAG_CAND_CAP;
+    } else {
+        const unsigned int raw_cnt = a.cnt[q];
+        if (raw_cnt > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
+        c = raw_cnt < CRAG_CAND_CAP ? (int)raw_cnt : CRAG_CAND_CAP;
+    }
     const int m = c < a.M ? c : a.M;  // candidates re-scored exactly
-    const unsigned long long* __restrict__ cq = a.cand + (long long)q * CRAG_CAND_CAP;
+    const unsigned long long* __restrict__ cq = a.cand + (long long)q * a.cand_stride;
+    auto cand_at = [&](int i) { return cq[seg ? seg_slot(seg_off, a.n_seg, a.seg_cap, i) : i]; };
     // skeys[0 .. m] = the m + 1 smallest candidates in (score, row) order (skeys[m], the best candidate NOT
     // re-scored, bounds the certificate).  Small buffers are sorted whole; big ones are first cut down to the
     // candidates whose score is <= the (m + 1)-th smallest score (selection), and only those are sorted.
     int c_sorted = c;
     if (c > 256) {
-        for (int i = tid; i < c; i += 1024) skeys[i] = cq[i];
+        for (int i = tid; i < c; i += 1024) skeys[i] = cand_at(i);
         __syncthreads();
         const uint32_t want = (uint32_t)(m < c ? m : c - 1);
         const uint32_t t = block_select([&](int i) { return (uint32_t)(skeys[i] >> 32); }, c, want, sel_scratch);
@@ -301,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             __syncthreads();
         }
     } else {
-        for (int i = tid; i < c; i += 1024) skeys[i] = cq[i];
+        for (int i = tid; i < c; i += 1024) skeys[i] = cand_at(i);
     }
     int P = 64;
     while (P < c_sorted) P <<= 1;
@@ -590,7 +644,7 @@ int crag_launch_kth(const KthArgs& a, hipStream_t s) {
 
 int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s) {
     const size_t lds = sizeof(unsigned long long) * (CRAG_CAND_CAP + CRAG_MAX_M) + sizeof(double) * 16 +
-                       sizeof(uint32_t) * (KTH_SCRATCH + 4);
+                       sizeof(uint32_t) * (KTH_SCRATCH + 4 + 1024 + 4);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -59,13 +59,22 @@ struct Qreg2Dma {
 __device__ __forceinline__ void q2_append(const f32x16_t& acc, const f32x16_t& xs, float c, float tq, unsigned mb,
                                           unsigned row_end, unsigned long long* __restrict__ cq, unsigned seg_cap,
                                           unsigned& pos) {
+    // called wave-uniformly; four rows at a time, skipped with one vote when none of them passes on any lane
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
-        const float s = fmaf(c, acc[r], xs[r]);
-        if (s <= tq && m < row_end) {
-            if (pos < seg_cap) cq[pos] = ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)m;
-            ++pos;
+    for (int g = 0; g < 4; ++g) {
+        float s[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = fmaf(c, acc[4 * g + e], xs[4 * g + e]);
+        const float mg = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+        if (__any(mg <= tq)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned m = mb + 8 * g + e;
+                if (s[e] <= tq && m < row_end) {
+                    if (pos < seg_cap) cq[pos] = ((unsigned long long)crag_fkey(s[e]) << 32) | (unsigned long long)m;
+                    ++pos;
+                }
+            }
         }
     }
 }
@@ -233,12 +242,12 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                         }
                     }
                 } else {
-                    if (hit0 || hit1) {
+                    {
                         int qa = q0;
                         asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path (not hoisted)
                         unsigned long long* cq = cand + (long long)qa * cand_stride + (long long)seg * seg_cap;
-                        if (hit0) q2_append(acc0, xs, e.c, tq0, mb, re, cq, (unsigned)seg_cap, pos0);
-                        if (hit1) q2_append(acc1, xs, e.c, tq1, mb, re, cq + 32ll * cand_stride, (unsigned)seg_cap, pos1);
+                        if (__any(hit0)) q2_append(acc0, xs, e.c, tq0, mb, re, cq, (unsigned)seg_cap, pos0);
+                        if (__any(hit1)) q2_append(acc1, xs, e.c, tq1, mb, re, cq + 32ll * cand_stride, (unsigned)seg_cap, pos1);
                     }
                     // vmcnt counts these stores too and they may retire out of order with the DMA loads, so the
                     // counted wait below would no longer prove that the next tile has landed: drain everything

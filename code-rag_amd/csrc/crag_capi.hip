@@ -327,7 +327,11 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             g.n_mid = qd[(size_t)b].n_mid;
             g.q_first = b;
             g.nq = e - b;
-            g.full_from = qd[(size_t)b].keep_mid ? g.n_mid : 0;  // same collection => same decision for the group
+            // same collection => same decisions for the whole group
+            const bool has_mid = g.n_mid > g.n_sample;
+            g.from[0] = 0;
+            g.from[1] = g.n_sample;
+            g.from[2] = has_mid ? (qd[(size_t)b].keep_mid ? g.n_mid : 0) : g.n_sample;
             max_nq = std::max(max_nq, g.nq);
             gd.push_back(g);
             b = e;
@@ -338,8 +342,8 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         for (int pass = 0; pass < 3; ++pass) {
             auto rows_of = [&](const GroupDesc& g) {
                 if (pass == 0) return g.n_sample;
-                if (pass == 1) return g.n_mid > g.n_sample ? g.n_mid : 0LL;  // level 1 only where it exists
-                return g.n_rows - g.full_from;
+                if (pass == 1) return g.n_mid > g.n_sample ? g.n_mid - g.from[1] : 0LL;  // level 1 only where it exists
+                return g.n_rows - g.from[2];
             };
             long long total_st = 0;
             for (auto& g : gd) total_st += (rows_of(g) + RT - 1) / RT;
@@ -446,6 +450,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
                                       : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
         }
+        if (P.blocks[pass] == 0) return 0;  // every row of every group is already behind an earlier level
         return crag_launch_scan_gemv(ga, pass, P.nq_template, P.blocks[pass], st);
     };
     if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
@@ -471,6 +476,8 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         k.segcnt = nullptr;
         k.n_seg = 0;
         k.seg_cap = 0;
+        k.seed_cand = P.mfma ? nullptr : cand;  // GEMV passes continue behind the sample rows
+        k.seed_cnt = P.mfma ? nullptr : cnt;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
     }
     // level 1: filtered scan of the first n1 rows -> tau1 (tightens tau0; never loosens it)
@@ -490,6 +497,8 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         k.segcnt = segcnt;
         k.n_seg = n_seg;
         k.seg_cap = seg_cap;
+        k.seed_cand = nullptr;
+        k.seed_cnt = nullptr;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 1) launch failed");
     }
     if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
@@ -543,7 +552,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         h0->prof[2] += 1.0;
         double scanned = 0.0;
         if (P.mfma) scanned = (double)(h0->n_rows - (qd[0].keep_mid ? qd[0].n_mid : 0));
-        for (const auto& g : gd) scanned += (double)(g.n_rows - g.full_from);
+        for (const auto& g : gd) scanned += (double)(g.n_rows - g.from[2]);
         h0->prof[3] += scanned;
     }
     h0->stats[0]++;

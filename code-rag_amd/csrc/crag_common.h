@@ -38,7 +38,10 @@ struct GroupDesc {
     int q_first, nq;
     int blk_first[3];  // per pass: 0 dense sample, 1 level-1 filter, 2 full filter
     int n_blk[3];
-    long long full_from;  // pass 2 scans rows [full_from, n_rows): n_mid when the level-1 candidates are kept, else 0
+    // first row of each pass: no row is scanned twice when the earlier levels' survivors stay in the buffer.
+    // from[0] = 0; from[1] = n_sample (k_kth seeds the buffer with the sample rows <= tau0);
+    // from[2] = n_mid (level-1 candidates kept) | n_sample (no level 1) | 0 (level 1 only set tau)
+    long long from[3];
 };
 
 // Everything the per-query kernels need (one per query of the batch).
@@ -142,6 +145,10 @@ struct KthArgs {
     float* tau;
     uint32_t* segcnt;  // segmented candidate buffer (see MfmaArgs) when n_seg > 0; then cnt / cnt_reset are unused
     int n_seg, seg_cap;
+    // level 0 only, may be null: append the sample rows with key <= tau to the (flat) candidate buffer, so
+    // that the later passes need not scan rows [0, n_sample) again
+    unsigned long long* seed_cand;
+    uint32_t* seed_cnt;
 };
 int crag_launch_kth(const KthArgs& a, hipStream_t s);
 struct FinalizeArgs {

@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     const float my_tau = mode ? tau[qg] : 0.f;
     const uint4* __restrict__ rows = (const uint4*)gp->rows;
 
-    // the full pass skips the rows level 1 already filtered into the buffer (full_from is a multiple of 128)
-    const long long t_first = pass == 2 ? gp->full_from / RT : 0;
+    // a pass skips the rows whose survivors are already in the buffer (from[] holds multiples of 128)
+    const long long t_first = gp->from[pass] / RT;
     for (long long t = t_first + w; t < n_st; t += n_waves) {
         const long long row0 = t * RT;
         const uint4* __restrict__ base = rows + row0 * C;

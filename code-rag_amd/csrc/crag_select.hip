@@ -218,11 +218,16 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     }
     __syncthreads();
     if (!seg && a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[q] = 0;  // kept: the full scan appends behind them
+    const uint32_t* __restrict__ src = a.src + (long long)q * a.q_stride + a.off0;
     if (n < (long long)a.M || (!from_cand && n == (long long)a.M)) {
         if (!from_cand && tid == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
+        if (!from_cand && a.seed_cand) {                           // ... and every sample row is seeded
+            for (int i = tid; i < (int)n; i += 1024)
+                a.seed_cand[(long long)q * CRAG_CAND_CAP + i] = ((unsigned long long)src[(long long)i * a.e_stride] << 32) | (unsigned)i;
+            if (tid == 0) a.seed_cnt[q] = (uint32_t)n;
+        }
         return;                                                    // from_cand: keep the looser tau
     }
-    const uint32_t* __restrict__ src = a.src + (long long)q * a.q_stride + a.off0;
     for (int i = tid; i < (int)n; i += 1024) {
         const int e = seg ? seg_slot(scratch, a.n_seg, a.seg_cap, i) : i;
         keys[i] = src[(long long)e * a.e_stride];
@@ -230,6 +235,15 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     __syncthreads();
     const uint32_t t = block_select([&](int i) { return keys[i]; }, (int)n, (uint32_t)a.M - 1u, scratch);
     if (tid == 0) a.tau[q] = crag_fkey_inv(t);
+    if (!from_cand && a.seed_cand) {  // sample row i IS row i of the collection; n <= 16384 = CRAG_CAND_CAP
+        for (int i = tid; i < (int)n; i += 1024) {
+            const uint32_t k = keys[i];
+            if (k <= t) {
+                const uint32_t pos = atomicAdd(&a.seed_cnt[q], 1u);
+                if (pos < CRAG_CAND_CAP) a.seed_cand[(long long)q * CRAG_CAND_CAP + pos] = ((unsigned long long)k << 32) | (unsigned)i;
+            }
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------

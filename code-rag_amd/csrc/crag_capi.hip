@@ -250,6 +250,30 @@ long long level1_rows(long long N, long long n0, int M) {
     return std::max(n0, std::min(n1, N));
 }
 
+// Filter levels of the multi-level cascade (segmented MFMA path): ascending row bounds, the last one == N;
+// level l scans rows [bound[l-1], bound[l]) (level 0 of the cascade, the dense sample, ends at n0).  Bounds grow
+// geometrically, n0 r^l, so every level is expected to add M r survivors; a level costs a launch and a
+// selection, so r ~ 12 unless the buffer would hold more than 3/4 of its capacity.
+std::vector<long long> cascade_bounds(long long N, long long n0, int M) {
+    std::vector<long long> nb;
+    if (N <= n0) return nb;
+    const double R = (double)N / (double)n0;
+    int L = (int)std::ceil(std::log(R) / std::log(12.0));
+    L = std::max(1, std::min(L, 4));
+    auto est = [&](int l) { return (double)l * (double)M * std::pow(R, 1.0 / l); };
+    while (L < 6 && est(L) > 0.75 * CRAG_CAND_CAP && est(L + 1) < est(L)) ++L;
+    const double r = std::pow(R, 1.0 / L);
+    double x = (double)n0;
+    for (int l = 1; l < L; ++l) {
+        x *= r;
+        long long b = ((long long)x + 127) / 128 * 128;
+        const long long prev = nb.empty() ? n0 : nb.back();
+        if (b > prev && b < N) nb.push_back(b);
+    }
+    nb.push_back(N);
+    return nb;
+}
+
 struct Plan {
     int B = 0, top_k = 0, kc = 0, M = 0;
     bool mfma = false;
@@ -286,6 +310,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 9));
 
     const bool mfma_v1 = P.mfma && !crag_qreg_supported(h0->dim_pad);  // k_scan_mfma always scans from row 0
+    // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics) and runs
+    // a multi-level cascade in which every level continues where the previous one stopped
+    const bool segmented = P.mfma && !mfma_v1 && B > 128;
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
     std::vector<GroupDesc> gd;
@@ -308,6 +335,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             const double est = (double)P.M * ((double)d.n_mid / (double)d.n_sample + (double)d.n_rows / (double)d.n_mid);
             d.keep_mid = est <= CRAG_CAND_CAP / 2 ? 1 : 0;
         }
+        if (segmented) d.keep_mid = 1;  // survivors of every level stay in the buffer
         P.sample_stride = std::max<long long>(P.sample_stride, d.n_sample);
         P.need_mid = P.need_mid || d.n_mid > d.n_sample;
     }
@@ -389,8 +417,6 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     uint32_t* sample = (uint32_t*)ws->sample.p;
     unsigned long long* cand = (unsigned long long*)ws->cand.p;
     HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)B, st));
-    // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics)
-    const bool segmented = qreg && B > 128;
     const int n_seg = segmented ? crag_qreg2_segments(B, h0->n_cus) : 0;
     // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64): the COUNT must stay <= CAP
     const int seg_cap = segmented ? std::max(64, 2 * CRAG_CAND_CAP / n_seg) : 0;
@@ -454,10 +480,72 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         return crag_launch_scan_gemv(ga, pass, P.nq_template, P.blocks[pass], st);
     };
     if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
+    double prof_rows = 0.0;  // rows the last (timed) filter launch scans
+    if (segmented) {
+        // level 0: dense sample of rows [0, n0) -> tau0; its rows at or below tau0 seed the segments
+        const long long N = h0->n_rows, n0 = qd[0].n_sample;
+        ma.row_begin = 0;
+        ma.row_end = n0;
+        if (crag_launch_scan_qreg2(ma, 0, h0->n_cus, st)) return fail(CRAG_E_HIP, "sample scan launch failed");
+        KthArgs k;
+        memset(&k, 0, sizeof(k));
+        k.src = sample;
+        k.q_stride = 1;
+        k.e_stride = bpad;
+        k.qd = qd_dev;
+        k.B = B;
+        k.M = P.M;
+        k.tau = tau;
+        k.seed_cand = cand;
+        k.seed_cnt = segcnt;
+        k.seed_n_seg = n_seg;
+        k.seed_seg_cap = seg_cap;
+        k.seed_stride = cand_stride;
+        if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
+        // filter levels [n0, n1), [n1, n2), ..., [.., N): each tightens tau from everything found so far
+        const std::vector<long long> nb = cascade_bounds(N, n0, P.M);
+        long long from = n0;
+        if (nb.empty() && prof) {
+            HIPCHK(hipEventRecord(ws->ev[1], st));
+            HIPCHK(hipEventRecord(ws->ev[2], st));
+            HIPCHK(hipEventRecord(ws->ev[3], st));
+        }
+        for (size_t l = 0; l < nb.size(); ++l) {
+            const bool last = l + 1 == nb.size();
+            if (last && prof) {
+                HIPCHK(hipEventRecord(ws->ev[1], st));
+                HIPCHK(hipEventRecord(ws->ev[2], st));
+            }
+            ma.row_begin = from;
+            ma.row_end = nb[l];
+            if (crag_launch_scan_qreg2(ma, 1, h0->n_cus, st)) return fail(CRAG_E_HIP, "filter scan launch failed");
+            if (last) {
+                if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+                prof_rows = (double)(nb[l] - from);
+            } else {
+                KthArgs k1;
+                memset(&k1, 0, sizeof(k1));
+                k1.src = (const uint32_t*)cand;
+                k1.q_stride = 2LL * cand_stride;
+                k1.e_stride = 2;
+                k1.off0 = 1;  // high word of the 64-bit key = ordered score
+                k1.qd = qd_dev;
+                k1.B = B;
+                k1.M = P.M;
+                k1.tau = tau;
+                k1.segcnt = segcnt;
+                k1.n_seg = n_seg;
+                k1.seg_cap = seg_cap;
+                if (crag_launch_kth(k1, st)) return fail(CRAG_E_HIP, "kth (filter level) launch failed");
+            }
+            from = nb[l];
+        }
+    } else {
     // level 0: dense sample -> tau0
     if (scan(0)) return fail(CRAG_E_HIP, "sample scan launch failed");
     {
         KthArgs k;
+        memset(&k, 0, sizeof(k));
         k.src = sample;
         if (P.mfma && qreg) {
             k.q_stride = 1;
@@ -468,14 +556,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         }
         k.off0 = 0;
         k.qd = qd_dev;
-        k.cnt = nullptr;
-        k.cnt_reset = nullptr;
         k.B = B;
         k.M = P.M;
         k.tau = tau;
-        k.segcnt = nullptr;
-        k.n_seg = 0;
-        k.seg_cap = 0;
         k.seed_cand = P.mfma ? nullptr : cand;  // GEMV passes continue behind the sample rows
         k.seed_cnt = P.mfma ? nullptr : cnt;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
@@ -484,6 +567,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if (P.need_mid) {
         if (scan(1)) return fail(CRAG_E_HIP, "level-1 scan launch failed");
         KthArgs k;
+        memset(&k, 0, sizeof(k));
         k.src = (const uint32_t*)cand;
         k.q_stride = 2LL * cand_stride;
         k.e_stride = 2;
@@ -494,11 +578,6 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         k.B = B;
         k.M = P.M;
         k.tau = tau;
-        k.segcnt = segcnt;
-        k.n_seg = n_seg;
-        k.seg_cap = seg_cap;
-        k.seed_cand = nullptr;
-        k.seed_cnt = nullptr;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 1) launch failed");
     }
     if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
@@ -506,6 +585,9 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
     if (scan(2)) return fail(CRAG_E_HIP, "full scan launch failed");
     if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+    if (P.mfma) prof_rows = (double)(h0->n_rows - (qd[0].keep_mid ? qd[0].n_mid : 0));
+    for (const auto& g : gd) prof_rows += (double)(g.n_rows - g.from[2]);
+    }
     FinalizeArgs f;
     f.qd = qd_dev;
     f.queries = q_dev;
@@ -550,10 +632,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         h0->prof[0] += ms0;
         h0->prof[1] += ms1;
         h0->prof[2] += 1.0;
-        double scanned = 0.0;
-        if (P.mfma) scanned = (double)(h0->n_rows - (qd[0].keep_mid ? qd[0].n_mid : 0));
-        for (const auto& g : gd) scanned += (double)(g.n_rows - g.from[2]);
-        h0->prof[3] += scanned;
+        h0->prof[3] += prof_rows;
     }
     h0->stats[0]++;
     h0->stats[1] += B;

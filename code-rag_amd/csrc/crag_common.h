@@ -149,6 +149,10 @@ struct KthArgs {
     // that the later passes need not scan rows [0, n_sample) again
     unsigned long long* seed_cand;
     uint32_t* seed_cnt;
+    // the same into a SEGMENTED buffer (seed_n_seg > 0): seed j goes to segment j % n_seg, slot j / n_seg, and
+    // seed_cnt is the segment counter array -- the scan workgroups then append behind the seeds
+    int seed_n_seg, seed_seg_cap;
+    long long seed_stride;
 };
 int crag_launch_kth(const KthArgs& a, hipStream_t s);
 struct FinalizeArgs {

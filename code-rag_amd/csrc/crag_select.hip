@@ -194,6 +194,27 @@ __device__ __forceinline__ int seg_slot(const uint32_t* segoff, int n_seg, int s
     return lo * seg_cap + (i - (int)segoff[lo]);
 }
 
+// level 0 seeds the candidate buffer with the sample rows at or below tau (KthArgs::seed_*): seed number j
+__device__ __forceinline__ void kth_seed(const KthArgs& a, int q, uint32_t j, uint32_t key, uint32_t row) {
+    const unsigned long long e = ((unsigned long long)key << 32) | row;
+    if (a.seed_n_seg > 0) {
+        const uint32_t sg = j % (uint32_t)a.seed_n_seg, slot = j / (uint32_t)a.seed_n_seg;
+        if (slot < (uint32_t)a.seed_seg_cap) a.seed_cand[(long long)q * a.seed_stride + (long long)sg * a.seed_seg_cap + slot] = e;
+    } else if (j < CRAG_CAND_CAP) {
+        a.seed_cand[(long long)q * CRAG_CAND_CAP + j] = e;
+    }
+}
+// ... and publishes how many there are (all threads of the block call this)
+__device__ __forceinline__ void kth_seed_counts(const KthArgs& a, int q, uint32_t total) {
+    const uint32_t tid = threadIdx.x;
+    if (a.seed_n_seg > 0) {
+        const uint32_t ns = (uint32_t)a.seed_n_seg;
+        for (uint32_t sg = tid; sg < ns; sg += 1024) a.seed_cnt[(long long)q * ns + sg] = total > sg ? (total - sg + ns - 1) / ns : 0u;
+    } else if (tid == 0) {
+        a.seed_cnt[q] = total;
+    }
+}
+
 // per query: tau = score of the M-th smallest ordered key of a strided list (KthArgs in crag_common.h);
 // any tau >= the true M-th smallest keeps the cascade exact (see block_select for when it is looser)
 __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
@@ -223,8 +244,9 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
         if (!from_cand && tid == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
         if (!from_cand && a.seed_cand) {                           // ... and every sample row is seeded
             for (int i = tid; i < (int)n; i += 1024)
-                a.seed_cand[(long long)q * CRAG_CAND_CAP + i] = ((unsigned long long)src[(long long)i * a.e_stride] << 32) | (unsigned)i;
-            if (tid == 0) a.seed_cnt[q] = (uint32_t)n;
+                kth_seed(a, q, (uint32_t)i, src[(long long)i * a.e_stride], (uint32_t)i);
+            __syncthreads();
+            kth_seed_counts(a, q, (uint32_t)n);
         }
         return;                                                    // from_cand: keep the looser tau
     }
@@ -236,13 +258,15 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     const uint32_t t = block_select([&](int i) { return keys[i]; }, (int)n, (uint32_t)a.M - 1u, scratch);
     if (tid == 0) a.tau[q] = crag_fkey_inv(t);
     if (!from_cand && a.seed_cand) {  // sample row i IS row i of the collection; n <= 16384 = CRAG_CAND_CAP
+        uint32_t* seed_total = scratch;  // block_select is done with its scratch
+        if (tid == 0) *seed_total = 0;
+        __syncthreads();
         for (int i = tid; i < (int)n; i += 1024) {
             const uint32_t k = keys[i];
-            if (k <= t) {
-                const uint32_t pos = atomicAdd(&a.seed_cnt[q], 1u);
-                if (pos < CRAG_CAND_CAP) a.seed_cand[(long long)q * CRAG_CAND_CAP + pos] = ((unsigned long long)k << 32) | (unsigned)i;
-            }
+            if (k <= t) kth_seed(a, q, atomicAdd(seed_total, 1u), k, (uint32_t)i);
         }
+        __syncthreads();
+        kth_seed_counts(a, q, *seed_total);
     }
 }
 

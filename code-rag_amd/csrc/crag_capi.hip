@@ -472,8 +472,14 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     auto scan = [&](int pass) -> int {
         if (P.mfma) {
             ma.row_end = pass == 0 ? qd[0].n_sample : (pass == 1 ? qd[0].n_mid : h0->n_rows);
-            ma.row_begin = pass == 2 && qd[0].keep_mid ? qd[0].n_mid : 0;
+            ma.row_begin = 0;
             if (!qreg) return crag_launch_scan_mfma(ma, pass ? 1 : 0, st);
+            // no row is scanned twice (as GroupDesc::from on the GEMV path): level 1 starts behind the seeded
+            // sample rows, the last pass behind whatever earlier level kept its survivors in the buffer
+            const bool has_mid = qd[0].n_mid > qd[0].n_sample;
+            if (pass == 1) ma.row_begin = qd[0].n_sample;
+            if (pass == 2) ma.row_begin = has_mid ? (qd[0].keep_mid ? qd[0].n_mid : 0) : qd[0].n_sample;
+            if (ma.row_begin >= ma.row_end) return 0;
             return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
                                       : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
         }
@@ -560,8 +566,8 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
         k.B = B;
         k.M = P.M;
         k.tau = tau;
-        k.seed_cand = P.mfma ? nullptr : cand;  // GEMV passes continue behind the sample rows
-        k.seed_cnt = P.mfma ? nullptr : cnt;
+        k.seed_cand = mfma_v1 ? nullptr : cand;  // later passes continue behind the sample rows
+        k.seed_cnt = mfma_v1 ? nullptr : cnt;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
     }
     // level 1: filtered scan of the first n1 rows -> tau1 (tightens tau0; never loosens it)
@@ -586,7 +592,11 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
     if (scan(2)) return fail(CRAG_E_HIP, "full scan launch failed");
     if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
-    if (P.mfma) prof_rows = (double)(h0->n_rows - (qd[0].keep_mid ? qd[0].n_mid : 0));
+    if (P.mfma) {
+        const bool has_mid = qd[0].n_mid > qd[0].n_sample;
+        const long long from2 = mfma_v1 ? 0 : (has_mid ? (qd[0].keep_mid ? qd[0].n_mid : 0) : qd[0].n_sample);
+        prof_rows = (double)(h0->n_rows - from2);
+    }
     for (const auto& g : gd) prof_rows += (double)(g.n_rows - g.from[2]);
     }
     FinalizeArgs f;

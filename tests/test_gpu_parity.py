@@ -354,7 +354,7 @@ def test_full_size_10m_bf16_properties():
     distance 0 in ascending id order, distances ascend, ids are distinct, and the reported
     distances agree with an fp64 recomputation of the returned rows."""
     import torch
-    n, d, nq, top_k = 10_000_000, 768, 32, 10
+    n, d, nq, top_k = 10_000_000, 768, 288, 10
     g = torch.Generator(device="cuda").manual_seed(1234)
     rows = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
     for lo in range(0, n, 1_000_000):
@@ -368,10 +368,13 @@ def test_full_size_10m_bf16_properties():
     col = ch.GpuCollection(d, "bf16", "l2")
     col.attach_device(rows)
     col.finalize()
-    for path in ("mfma", "gemv"):
+    first4 = {}
+    # one-block MFMA scan (B = 32), two-block MFMA scan with a ragged second query group (B = 288), GEMV (B = 4)
+    for path, nb in (("mfma", 32), ("mfma", 288), ("gemv", 4)):
         col.set_path(path)
-        qq = q if path == "mfma" else q[:4].contiguous()
+        qq = q[:nb].contiguous()
         ids, sc, di, cn = [t.cpu().numpy() for t in col.search_device(qq, top_k, 2.0)]
+        first4[(path, nb)] = (ids[:4].copy(), di[:4].copy(), sc[:4].copy())
         assert list(ids[0, :3]) == sorted(planted) and np.all(di[0, :3] == 0.0) and np.all(sc[0, :3] == 1.0)
         for b in range(len(qq)):
             assert int(cn[b]) == top_k and len(set(ids[b])) == top_k
@@ -383,6 +386,11 @@ def test_full_size_10m_bf16_properties():
         # the 10th distance must not exceed the 10th smallest of an independent fp32 brute force
         approx = torch.cdist(qq[:2].float(), rows[:2_000_000].float()).pow(2).topk(top_k, largest=False).values
         assert np.all(di[:2, -1] <= approx[:, -1].cpu().numpy() + 1e-5)
+    # three independent scan kernels must agree bit for bit on the queries they share
+    ref = first4[("gemv", 4)]
+    for key, got in first4.items():
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), key
     assert col.stats()["fallback"] == 0
 
 

@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));  // ~ +-0.01..0.03
     for (long long off = 0; off < n * D; off += h.size()) hipMemcpy(rows + off, h.data(), std::min<long long>(h.size(), n * D - off) * 2, hipMemcpyHostToDevice);
     hipMemcpy(q, h.data(), 1024 * D * 2, hipMemcpyHostToDevice);
+    if (argc > 2 && argv[2][0] == 'z') hipMemset(rows, 0, n * D * 2);  // all-zero corpus: least data toggling
     hipMemset(xn, 0, (n + 512) * 4); hipMemset(cnt, 0, 4 * (1024 * 512 + 64));
     std::vector<float> t(1024, -1e30f); hipMemcpy(tau, t.data(), 4096, hipMemcpyHostToDevice);
     MfmaArgs a; a.rows = rows; a.xnorm = xn; a.n_rows = n; a.row_begin = 0; a.row_end = n; a.queries = q; a.n_queries = B;

@@ -38,6 +38,17 @@ int fail(int code, const std::string& msg) {
                                         ":" + std::to_string(__LINE__) + ")");                            \
     } while (0)
 
+// Waits for a stream by polling: hipStreamSynchronize parks the thread and its wake-up costs tens of
+// microseconds, which is a tenth of a batch-1 search; a search call owns its host thread anyway.
+inline hipError_t stream_wait(hipStream_t st) {
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (spins > 200000) return hipStreamSynchronize(st);  // a long wait (> ~50 ms): stop burning the core
+        __builtin_ia32_pause();
+    }
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -634,7 +645,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
     uint32_t* hst = ws->pinned_status;
     HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(st));
     if (prof) {
         float ms0 = 0.f, ms1 = 0.f;
         HIPCHK(hipEventElapsedTime(&ms0, ws->ev[0], ws->ev[1]));

@@ -395,11 +395,26 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     } else {
         for (int i = tid; i < c; i += 1024) skeys[i] = cand_at(i);
     }
-    int P = 64;
-    while (P < c_sorted) P <<= 1;
-    for (int i = c_sorted + tid; i < P; i += 1024) skeys[i] = ~0ull;
     __syncthreads();
-    bitonic_sort_u64(skeys, P);
+    if (c_sorted <= 1024) {
+        // rank by counting (keys are unique: the row id is part of the key): every thread reads the same LDS
+        // word at a time (broadcast), two barriers in all -- a bitonic network of this size costs 21-55
+        unsigned long long k = ~0ull;
+        int rank = 0;
+        if (tid < c_sorted) {
+            k = skeys[tid];
+            for (int j = 0; j < c_sorted; ++j) rank += skeys[j] < k ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < c_sorted) skeys[rank] = k;
+        __syncthreads();
+    } else {
+        int P = 2048;
+        while (P < c_sorted) P <<= 1;
+        for (int i = c_sorted + tid; i < P; i += 1024) skeys[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_u64(skeys, P);
+    }
     const size_t esz = a.dtype == CRAG_F32 ? 4 : 2;
     const void* qv = (const char*)a.queries + (size_t)q * a.dim_pad * esz;
 
@@ -423,20 +438,33 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     }
     const double qn = red[0];
 
-    // exact re-scoring: 8 lanes per candidate
-    for (int base = 0; base < m; base += (int)(blockDim.x >> 3)) {
-        const int i = base + (tid >> 3);
-        const int j = tid & 7;
-        double acc = 0.0;
-        uint32_t row = 0;
-        if (i < m) {
-            row = (uint32_t)(skeys[i] & 0xffffffffull);
-            acc = canon_lane(D.rows, qv, a.dtype, a.dim, j, a.metric, (long long)row * a.dim_pad);
-        }
-        acc = combine8(acc);
-        if (i < m && j == 0) {
-            const double dist = a.metric == CRAG_L2 ? acc : __dsub_rn(1.0, acc);
-            ekeys[i] = ((unsigned long long)crag_fkey((float)dist) << 32) | row;
+    // exact re-scoring: 8 lanes per candidate.  The query and the candidates' rows are first staged in LDS with
+    // coalesced 16-byte loads, all in flight at once (the sorted keys occupy skeys[0 .. m]; the rest of that
+    // 128-KiB region is free now), so the order-defining add chains read LDS instead of chasing 2-byte loads
+    {
+        unsigned char* stage_q = (unsigned char*)(skeys + 1024);  // m + 1 <= CRAG_MAX_M + 1 <= 1024 keys stay live
+        unsigned char* stage_r = stage_q + 4096;                  // dim_pad * esz <= 4096
+        const int row_bytes = a.dim_pad * (int)esz, chunks = row_bytes >> 4;
+        int rpr = (int)((sizeof(unsigned long long) * (CRAG_CAND_CAP - 1024) - 4096) / (size_t)row_bytes);
+        if (rpr > 128) rpr = 128;  // 1024 threads / 8 lanes
+        for (int c = tid; c < chunks; c += 1024) ((uint4*)stage_q)[c] = ((const uint4*)qv)[c];
+        for (int base = 0; base < m; base += rpr) {
+            const int nr = m - base < rpr ? m - base : rpr;
+            __syncthreads();  // the previous round's readers are done
+            for (int idx = tid; idx < nr * chunks; idx += 1024) {
+                const int r = idx / chunks, c = idx - r * chunks;
+                const uint32_t row = (uint32_t)(skeys[base + r] & 0xffffffffull);
+                ((uint4*)stage_r)[idx] = ((const uint4*)D.rows)[(long long)row * chunks + c];
+            }
+            __syncthreads();
+            const int r = tid >> 3, j = tid & 7;
+            double acc = 0.0;
+            if (r < nr) acc = canon_lane(stage_r, stage_q, a.dtype, a.dim, j, a.metric, (long long)r * a.dim_pad);
+            acc = combine8(acc);
+            if (r < nr && j == 0) {
+                const double dist = a.metric == CRAG_L2 ? acc : __dsub_rn(1.0, acc);
+                ekeys[base + r] = ((unsigned long long)crag_fkey((float)dist) << 32) | (uint32_t)(skeys[base + r] & 0xffffffffull);
+            }
         }
     }
     __syncthreads();

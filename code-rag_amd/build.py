@@ -16,9 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_scan_qreg2.hip", "crag_select.hip",
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_select.hip",
            "crag_capi.hip"]
-INCLUDES = {"crag_scan_qreg.hip": ["crag_qreg_kloop.inc"], "crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"]}
+INCLUDES = {"crag_scan_qreg.hip": ["crag_qreg_kloop.inc"], "crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
+            "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -32,16 +33,17 @@ def _newer(target, deps):
 _REG = re.compile(r"\b([av])(?:(\d+)\b|\[(\d+):(\d+)\])")
 
 
-def check_qreg2_isa(asm_path):
-    """crag_scan_qreg2.hip keeps its query fragments in fixed registers the compiler is not told about
-    (gen_qreg2_kloop.py: all AGPRs, and v[128:255] at KS = 48).  The generated statements list them as
-    clobbers, so nothing of the compiler's lives there ACROSS a statement; this check proves on the
-    emitted ISA that no compiler-generated instruction touches them BETWEEN statements either."""
-    kernel, in_asm, bad, seen = None, False, [], set()
+def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from):
+    """crag_scan_qreg2.hip and crag_scan_qsplit.hip keep their query fragments in fixed registers the compiler
+    is not told about (gen_qreg2_kloop.py / gen_qsplit_kloop.py: all AGPRs, and for qreg2 at KS = 48 also
+    v[128:255]).  The generated statements list them as clobbers, so nothing of the compiler's lives there
+    ACROSS a statement; this check proves on the emitted ISA that no compiler-generated instruction touches
+    them BETWEEN statements either.  hidden_vgpr_from(match) -> first hidden VGPR of that kernel, or None."""
+    kernel, in_asm, bad, seen, vlim = None, False, [], set(), None
     for n, line in enumerate(open(asm_path), 1):
-        m = re.match(r"^(_Z\S*k_scan_qreg2ILi(\d+)ELi\d+E\S*):", line)
+        m = re.match(kernel_re, line)
         if m:
-            kernel, ks, in_asm = m.group(1), int(m.group(2)), False
+            kernel, in_asm, vlim = m.group(1), False, hidden_vgpr_from(m)
             seen.add(kernel)
             continue
         if kernel is None:
@@ -57,12 +59,21 @@ def check_qreg2_isa(asm_path):
             code = line.split(";")[0]
             for f, one, lo, hi in _REG.findall(code):
                 top = int(one) if one else int(hi)
-                if f == "a" or (ks == 48 and top >= 128):
+                if f == "a" or (vlim is not None and top >= vlim):
                     bad.append(f"{asm_path}:{n}: {line.strip()}")
-    if len(seen) < 8:
-        raise RuntimeError(f"check_qreg2_isa: expected 8 k_scan_qreg2 kernels in {asm_path}, found {len(seen)}")
+    if len(seen) != n_kernels:
+        raise RuntimeError(f"check_fixed_register_isa: expected {n_kernels} kernels in {asm_path}, found {len(seen)}")
     if bad:
-        raise RuntimeError("check_qreg2_isa: compiler code touches the fixed fragment registers:\n" + "\n".join(bad[:20]))
+        raise RuntimeError("check_fixed_register_isa: compiler code touches the fixed fragment registers:\n" + "\n".join(bad[:20]))
+
+
+def check_qreg2_isa(asm_path):
+    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qreg2ILi(\d+)ELi\d+E\S*):", 8,
+                             lambda m: 128 if int(m.group(2)) == 48 else None)
+
+
+def check_qsplit_isa(asm_path):
+    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qsplitILi\d+E\S*):", 2, lambda m: None)
 
 
 def build(force=False, verbose=True):
@@ -77,8 +88,8 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or not _newer(obj, [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]):
             jobs.append(["hipcc"] + FLAGS + ["-c", src, "-o", obj])
-            if s == "crag_scan_qreg2.hip":  # device ISA of the same compilation, for check_qreg2_isa
-                jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", os.path.join(OBJ, "crag_scan_qreg2.s")])
+            if s in ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip"):  # device ISA of the same compilation, for the checks
+                jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", os.path.join(OBJ, s.replace(".hip", ".s"))])
 
     def run(cmd):
         if verbose:
@@ -89,6 +100,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
+    check_qsplit_isa(os.path.join(OBJ, "crag_scan_qsplit.s"))
     if jobs or not os.path.exists(LIB):
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -321,10 +321,11 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     const int path = h0->force_path;
     P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 9));
 
-    const bool mfma_v1 = P.mfma && !crag_qreg_supported(h0->dim_pad);  // k_scan_mfma always scans from row 0
+    const bool qsplit = P.mfma && crag_qsplit_supported(h0->dim_pad);  // 1024-element rows: flat buffers, row-major sample
+    const bool mfma_v1 = P.mfma && !crag_qreg_supported(h0->dim_pad) && !qsplit;  // k_scan_mfma always scans from row 0
     // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics) and runs
     // a multi-level cascade in which every level continues where the previous one stopped
-    const bool segmented = P.mfma && !mfma_v1 && B > 128;
+    const bool segmented = P.mfma && crag_qreg_supported(h0->dim_pad) && B > 128;
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
     std::vector<GroupDesc> gd;
@@ -414,7 +415,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if ((rc = ws->desc.ensure(desc_bytes))) return rc;
     if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
     if ((rc = ws->cntst.ensure(sizeof(uint32_t) * 2 * (size_t)B))) return rc;
-    const bool qreg = P.mfma && crag_qreg_supported(h0->dim_pad);
+    const bool qreg = P.mfma && (crag_qreg_supported(h0->dim_pad) || qsplit);
     const long long bpad = ((long long)B + 15) / 16 * 16;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
     if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * CRAG_CAND_CAP))) return rc;
@@ -491,6 +492,7 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
             if (pass == 1) ma.row_begin = qd[0].n_sample;
             if (pass == 2) ma.row_begin = has_mid ? (qd[0].keep_mid ? qd[0].n_mid : 0) : qd[0].n_sample;
             if (ma.row_begin >= ma.row_end) return 0;
+            if (qsplit) return crag_launch_scan_qsplit(ma, pass ? 1 : 0, h0->n_cus, st);
             return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
                                       : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
         }
@@ -1133,13 +1135,15 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.metric = h->metric;
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = stride;
-        if (crag_qreg_supported(h->dim_pad)) {
+        if (crag_qreg_supported(h->dim_pad) || crag_qsplit_supported(h->dim_pad)) {
             rowmajor = true;
             bpad = ((long long)B + 15) / 16 * 16;
             if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)std::max<long long>(n, 1)))) return rc;
             a.sample = (uint32_t*)ws->sample.p;
             a.sample_stride = bpad;
-            if (B > 128 ? crag_launch_scan_qreg2(a, 0, h->n_cus, st) : crag_launch_scan_qreg(a, 0, h->n_cus, st))
+            if (crag_qsplit_supported(h->dim_pad) ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
+                : B > 128                          ? crag_launch_scan_qreg2(a, 0, h->n_cus, st)
+                                                   : crag_launch_scan_qreg(a, 0, h->n_cus, st))
                 return fail(CRAG_E_HIP, "qreg launch failed");
         } else if (crag_launch_scan_mfma(a, 0, st)) {
             return fail(CRAG_E_HIP, "mfma launch failed");

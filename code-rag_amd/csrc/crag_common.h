@@ -122,6 +122,9 @@ int crag_launch_scan_mfma(const MfmaArgs& a, int mode, hipStream_t s);
 // query-stationary MFMA scan (dim_pad in {256,384,512,768}); its sample is ROW-major [row][stride]
 bool crag_qreg_supported(int dim_pad);
 int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip
+bool crag_qsplit_supported(int dim_pad);
+int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // same contract, 256 queries per workgroup (two 32-query blocks per wave): the choice for B > 128
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)

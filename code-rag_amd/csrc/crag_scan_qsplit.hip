@@ -1,0 +1,264 @@
+// K2 (split-K query-stationary form): MFMA scan for B >= 9 query batches over 1024-element bf16 rows
+// (768 < dim_pad <= 1024), gfx950.
+//
+// Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
+// /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
+//
+// Same dataflow as crag_scan_qreg.hip: four waves (one per SIMD) x 32 stationary queries, corpus tiles of
+// 32 rows streamed HBM -> LDS by LDS-DMA, fused threshold filter with the query on the lane.  A 32-row tile
+// of 2-KiB rows does not fit a three-deep LDS ring, so it travels as two half-tiles of 32 rows x 512
+// elements (K-parts) through a ring of FOUR 32-KiB buffers, three half-tiles in flight; one generated
+// statement (crag_qsplit_kloop.inc, gen_qsplit_kloop.py holds the register contract and the wait counts)
+// multiplies both K-parts of a tile into one accumulator, with the mid-tile rendezvous inside.  The 64
+// query fragments fill all 256 AGPRs (fixed registers outside the compiler's allocation, checked on the
+// emitted ISA by build.py).  Candidate appends use the flat buffer + returning atomic of crag_scan_qreg.hip.
+//
+//   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced)
+//   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
+#include "crag_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int QS_TM = 32;        // corpus rows per tile
+constexpr int QS_WAVES = 4;      // waves per workgroup: one per SIMD
+constexpr int QS_QPB = 32 * QS_WAVES;
+constexpr int QS_D = 1024;       // elements per (padded) row
+constexpr int QS_GROWB = QS_D * 2;   // bytes per row in memory
+constexpr int QS_HROWB = 1024;       // bytes per row of a half-tile in LDS (512 elements)
+constexpr int QS_HALF = QS_TM * QS_HROWB;  // bytes per LDS buffer
+constexpr int QS_NBUF = 4;
+constexpr int QS_XN_BYTES = 256;
+constexpr int QS_XN_BASE = QS_NBUF * QS_HALF;  // |x|^2 slots: [buffer][wave][64 floats]
+constexpr int QS_DMA_PER_HALF = 9;   // per wave: 8 row pieces + the |x|^2 column
+
+struct QsplitEpi {
+    float c, w;       // score = c * (q . x) + w * |x|^2   (l2: -2, 1; ip: -1, 0)
+    unsigned xaddr;   // LDS address of the lane's |x|^2 run
+};
+struct QsplitDma {            // one half-tile to prefetch (all wave-uniform)
+    const unsigned char* lo;  // first byte of the half-tile's rows 0..15 (row stride QS_GROWB)
+    const unsigned char* hi;  // ... rows 16..31
+    unsigned lds_dst;         // LDS byte address of this wave's first row piece in the target buffer
+    const float* xn;          // |x|^2 of the tile's first row
+    unsigned xn_dst;          // LDS byte address of this wave's |x|^2 slot of the target buffer
+};
+
+#include "crag_qsplit_kloop.inc"
+
+template <int MODE>
+__global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned short* __restrict__ rows,
+                                                                  const float* __restrict__ xnorm, long long row_begin,
+                                                                  long long row_end, const unsigned short* __restrict__ queries,
+                                                                  int n_queries, int nqg, int metric,
+                                                                  const float* __restrict__ tau, uint32_t* __restrict__ sample,
+                                                                  long long sample_stride, unsigned long long* __restrict__ cand,
+                                                                  uint32_t* __restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];  // the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // workgroup -> (query group, row-tile stream); workgroups with equal blockIdx % 8 share an XCD
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int qg = j % nqg;
+    const int stream = j / nqg;
+    const int n_streams = (int)(gridDim.x >> 3) / nqg;
+    const long long n_tiles = (row_end + QS_TM - 1) / QS_TM;
+    const long long t_step = (long long)n_streams * 8;
+    long long t = row_begin / QS_TM + (long long)stream * 8 + xcd;  // row_begin: a multiple of the tile height
+
+    const int q_base = qg * QS_QPB + wave * 32;
+    const bool wave_active = q_base < n_queries;  // wave-uniform
+    const int my_q = q_base + fr;
+    const bool q_ok = my_q < n_queries;
+    // stationary B operand: this lane's query, k = 16 s + 8 fh + [0,8), in fixed AGPRs
+    qsplit_load(queries + (long long)(q_ok ? my_q : n_queries - 1) * QS_D + 8 * fh);
+    float tq = -__builtin_inff();
+    if (MODE == 1 && q_ok) tq = tau[my_q];
+
+    // LDS-DMA: a wave moves rows wave + 4 i and wave + 4 i + 16 (i < 4) of a half-tile, one 1-KiB piece per
+    // row; LDS position p of row r holds chunk p ^ (r & 15), rows r and r + 16 swizzle alike
+    unsigned voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave + QS_WAVES * i;
+        voff[i] = (unsigned)(r * QS_GROWB + ((lane ^ (r & 15)) << 4));
+    }
+    const unsigned xoff = lane * 4;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto half_desc = [&](long long tile, int part, int buf) {
+        QsplitDma d;
+        d.lo = (const unsigned char*)rows + tile * (long long)(QS_TM * QS_GROWB) + part * QS_HROWB;
+        d.hi = d.lo + 16 * QS_GROWB;
+        d.lds_dst = lds_base + buf * QS_HALF + wave * QS_HROWB;
+        d.xn = xnorm + tile * QS_TM;
+        d.xn_dst = lds_base + QS_XN_BASE + (buf * QS_WAVES + wave) * QS_XN_BYTES;
+        return d;
+    };
+    // C++ issue of one half-tile (prologue, inactive waves, ragged last tile): exactly QS_DMA_PER_HALF instructions
+    auto issue = [&](long long tile, int part, int buf) {
+        const long long row0 = tile * QS_TM;
+        const unsigned char* tb = (const unsigned char*)rows + row0 * (long long)QS_GROWB + part * QS_HROWB;
+        const bool whole = row0 + QS_TM <= row_end;
+        const unsigned r_last = (unsigned)(row_end - 1 - row0);  // ragged tile only: its last valid row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned off = voff[i] + h * 16 * QS_GROWB;
+                if (!whole) {  // rows past the end re-read the last row (never past the matrix)
+                    asm volatile("" : "+v"(off));
+                    const unsigned r = off / QS_GROWB;
+                    if (r > r_last) off -= (r - r_last) * QS_GROWB;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + off),
+                                                 (__attribute__((address_space(3))) void*)(lds + buf * QS_HALF + (wave + QS_WAVES * i + 16 * h) * QS_HROWB),
+                                                 16, 0, 0);
+            }
+        }
+        const float* gx = xnorm + row0 + lane;  // xnorm is padded by >= 256 floats
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
+                                         (__attribute__((address_space(3))) void*)(lds + QS_XN_BASE + (buf * QS_WAVES + wave) * QS_XN_BYTES),
+                                         4, 0, 0);
+    };
+
+    const unsigned a_lane = lds_base + fr * QS_HROWB + ((fh ^ (fr & 15)) << 4);
+    const unsigned x_lane = lds_base + QS_XN_BASE + wave * QS_XN_BYTES + 16 * fh;
+    QsplitEpi e;
+    e.c = metric == CRAG_L2 ? -2.f : -1.f;
+    e.w = metric == CRAG_L2 ? 1.f : 0.f;
+
+    // half-tile h of this workgroup's sequence lives in buffer h % 4; tile i = half-tiles 2 i (part 0) and 2 i + 1.
+    // prologue: half-tiles 0, 1, 2 in flight, wait for the first
+    int cur = 0;  // buffer of the current tile's part 0: 0 or 2
+    if (t < n_tiles) {
+        issue(t, 0, 0);
+        issue(t, 1, 1);
+    }
+    if (t + t_step < n_tiles) {
+        issue(t + t_step, 0, 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QS_DMA_PER_HALF) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    for (; t < n_tiles; t += t_step) {
+        const long long t1 = t + t_step, t2 = t + 2 * t_step;
+        const bool ex3 = t1 < n_tiles, ex4 = t2 < n_tiles;  // half-tiles h + 3 (next tile, part 1) / h + 4 exist
+        const int b1 = cur + 1, b3 = (cur + 3) & 3, b4 = cur;  // buffers of h + 1, h + 3, h + 4
+        const bool dma0 = ex3 && wave_active && (t1 + 1) * QS_TM <= row_end;
+        const bool dma1 = ex4 && wave_active && (t2 + 1) * QS_TM <= row_end;
+        bool drained = false;  // this wave's end-of-tile wait must be vmcnt(0)
+        if (wave_active) {
+            if (ex3 && !dma0) issue(t1, 1, b3);  // ragged next tile: up front (buffer h + 3 = h - 1 is free)
+            const unsigned a0 = a_lane + cur * QS_HALF, a1 = a_lane + b1 * QS_HALF;
+            e.xaddr = x_lane + b1 * (QS_WAVES * QS_XN_BYTES);
+            f32x16_t acc, xs;
+            float mn;
+            QsplitDma d0 = half_desc(t1, 1, b3), d1 = half_desc(t2, 0, b4);
+            if (dma0 && dma1) QsplitTile<true, true>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            else if (dma0) QsplitTile<true, false>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            else if (dma1) QsplitTile<false, true>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            else QsplitTile<false, false>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            if (ex4 && !dma1) issue(t2, 0, b4);  // ragged: after the mid-tile rendezvous freed buffer h
+            drained = !(dma0 && dma1);
+            const unsigned mb = (unsigned)t * QS_TM + 4 * fh, re = (unsigned)row_end;  // rows per collection < 2^32
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned m = mb + 8 * (r >> 2) + (r & 3);
+                    if (q_ok && m < re) sample[m * sample_stride + my_q] = crag_fkey(fmaf(e.c, acc[r], xs[r]));
+                }
+                drained = true;
+            } else if (__any(mn <= tq)) {
+                // one returning atomic per lane (= per query) for all of its passing rows
+                int npass = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned m = mb + 8 * (r >> 2) + (r & 3);
+                    npass += (fmaf(e.c, acc[r], xs[r]) <= tq && m < re) ? 1 : 0;
+                }
+                if (npass) {
+                    int qa = my_q;
+                    asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path
+                    unsigned pos = atomicAdd(&cnt[qa], (unsigned)npass);
+                    unsigned long long* cq = cand + (long long)qa * CRAG_CAND_CAP;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
+                        const float s = fmaf(e.c, acc[r], xs[r]);
+                        if (s <= tq && m < re) {
+                            if (pos < CRAG_CAND_CAP) cq[pos] = ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)m;
+                            ++pos;
+                        }
+                    }
+                }
+                drained = true;  // vmcnt counts these stores and atomics too, out of order with the DMA loads
+            }
+        } else {
+            // a wave without queries still moves its share of every half-tile and keeps both rendezvous
+            if (ex3) {
+                issue(t1, 1, b3);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QS_DMA_PER_HALF) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (ex4) issue(t2, 0, b4);
+            drained = !(ex3 && ex4);
+        }
+        // half-tile h + 2 (the next tile's part 0) must have landed in every wave's view: each wave retires all
+        // but the two half-tiles it issued after that one (h + 3 and h + 4), then the rendezvous
+        if (drained) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QS_DMA_PER_HALF) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        cur ^= 2;
+    }
+}
+
+int launch_mode(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
+    const size_t lds = (size_t)QS_NBUF * QS_HALF + (size_t)QS_NBUF * QS_WAVES * QS_XN_BYTES;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[mode]) {
+        if (mode == 0)
+            (void)hipFuncSetAttribute((const void*)k_scan_qsplit<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void*)k_scan_qsplit<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[mode] = true;
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL((k_scan_qsplit<0>), dim3(grid), dim3(64 * QS_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
+                           a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau,
+                           a.sample, a.sample_stride, a.cand, a.cnt);
+    else
+        hipLaunchKernelGGL((k_scan_qsplit<1>), dim3(grid), dim3(64 * QS_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
+                           a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau,
+                           a.sample, a.sample_stride, a.cand, a.cnt);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool crag_qsplit_supported(int dim_pad) { return dim_pad == QS_D; }
+
+// sample layout of this kernel: sample[row * sample_stride + query]  (row-major), as crag_launch_scan_qreg
+int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
+    if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
+    if (a.row_begin % QS_TM || a.dim_pad != QS_D) return -1;
+    const int nqg = (a.n_queries + QS_QPB - 1) / QS_QPB;
+    if (nqg > 32) return -1;
+    int streams = (n_cus / 8) / nqg;  // row-tile streams per XCD
+    if (streams < 1) streams = 1;
+    const long long n_tiles = (a.row_end - a.row_begin + QS_TM - 1) / QS_TM;
+    while (streams > 1 && (long long)streams * 8 > n_tiles) --streams;
+    return launch_mode(a, mode, 8 * streams * nqg, nqg, s);
+}

@@ -133,6 +133,9 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (384, 8000, 150, 10, "ip"),
     (256, 3001, 257, 10, "l2"),             # second query group holds one query
     (768, 20000, 300, 10, "ip"),
+    (1024, 30011, 200, 10, "ip"),           # 1024-element rows: split-K scan, ragged last tile, two query groups
+    (1000, 9000, 17, 10, "l2"),             # padded to 1024; one partly filled wave
+    (1024, 40, 9, 10, "l2"),                # a single ragged tile
 ])
 def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)
@@ -150,7 +153,7 @@ def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
 @pytest.mark.parametrize("dtype,d,nq,path", [("f32", 384, 3, "gemv"), ("bf16", 768, 8, "gemv"), ("bf16", 768, 40, "mfma"),
                                               ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma"),
                                               ("bf16", 768, 150, "mfma"), ("bf16", 384, 129, "mfma"), ("bf16", 512, 256, "mfma"),
-                                              ("bf16", 256, 192, "mfma")])
+                                              ("bf16", 256, 192, "mfma"), ("bf16", 1000, 140, "mfma"), ("bf16", 1024, 9, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

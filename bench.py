@@ -156,7 +156,7 @@ def main():
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
     roofline = {
-        "kernel": ("k_scan_qreg2" if B > 128 else "k_scan_qreg" if B >= 9 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
+        "kernel": ("k_scan_qreg2" if B > 128 else "k_scan_qreg" if B >= 3 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,
@@ -212,6 +212,7 @@ def extra_regimes(col, q, n, d, torch):
     """batch-1 (HBM-bound GEMV) and batch-1024 top-100 (MFMA-bound GEMM) on the same corpus."""
     out = []
     for name, B, top_k, path, steps in (("batch-1 top-10 GEMV", 1, 10, "gemv", 20), ("batch-8 top-10 GEMV", 8, 10, "gemv", 10),
+                                        ("batch-8 top-10 one-block MFMA (what auto picks from 3 queries up)", 8, 10, "mfma", 10),
                                         ("batch-1024 top-100 MFMA", 1024, 100, "mfma", 5)):
         col.set_path(path)
         qb = q[:B].contiguous()

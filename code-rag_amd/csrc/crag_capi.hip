@@ -319,7 +319,10 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     if (P.M > CRAG_MAX_M) P.M = CRAG_MAX_M;
 
     const int path = h0->force_path;
-    P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= 9));
+    // auto: the query-stationary MFMA kernels hold ~5.2-5.7 TB/s from 2 queries up, the GEMV loses bandwidth with
+    // every query it adds (tools/sweep_small_batch.py: MFMA ahead from B = 2-3 on 384/768/1024-element bf16 rows)
+    const int mfma_from = (crag_qreg_supported(h0->dim_pad) || crag_qsplit_supported(h0->dim_pad)) ? 3 : 9;
+    P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && crag_qsplit_supported(h0->dim_pad);  // 1024-element rows: flat buffers, row-major sample
     const bool mfma_v1 = P.mfma && !crag_qreg_supported(h0->dim_pad) && !qsplit;  // k_scan_mfma always scans from row 0

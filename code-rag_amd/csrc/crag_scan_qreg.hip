@@ -1,4 +1,4 @@
-// K2 (query-stationary form): MFMA scan for 9 <= B query batches, bf16, dim_pad <= 768, gfx950.
+// K2 (query-stationary form): MFMA scan for 3 <= B <= 128 query batches, bf16, dim_pad <= 768, gfx950.
 //
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.

@@ -307,9 +307,38 @@ struct MergeOut {
 };
 
 // one batch on one device: queries already on the device in index dtype, row stride dim_pad
+int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
+                         const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
+                         hipStream_t st, const MergeOut* mo);
+
+// Batches of any size: the kernels take at most CRAG_MAX_CHUNK queries per launch sequence (query groups per
+// launch, candidate-buffer memory), so larger batches run as consecutive chunks on the same stream.
+constexpr int CRAG_MAX_CHUNK = 2048;
 int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                    const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
                    hipStream_t st, const MergeOut* mo = nullptr) {
+    for (int off = 0; off < B; off += CRAG_MAX_CHUNK) {
+        const int nb = std::min(CRAG_MAX_CHUNK, B - off);
+        const crag_index* h0 = hs[off];
+        MergeOut m;
+        if (mo) {
+            m = *mo;
+            m.ids += (size_t)off * top_k;
+            m.scores += (size_t)off * top_k;
+            m.dist += (size_t)off * top_k;
+            m.counts += off;
+        }
+        const int rc = search_entries_chunk(hs + off, same_handle, (const char*)q_dev + (size_t)off * h0->dim_pad * h0->esz, nb, top_k,
+                                            qh_dev, qhoff_dev ? qhoff_dev + off : nullptr, entries_dev + (size_t)off * 2 * top_k,
+                                            ws, st, mo ? &m : nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
+                         const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
+                         hipStream_t st, const MergeOut* mo) {
     crag_index* h0 = hs[0];
     Plan P;
     P.B = B;

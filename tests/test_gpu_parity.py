@@ -182,6 +182,14 @@ def test_small_and_ragged_collections(coracle, n):
     check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
 
 
+@pytest.mark.parametrize("dtype,d", [("bf16", 768), ("f32", 384)])
+def test_batches_larger_than_a_chunk(coracle, dtype, d):
+    """More queries than the library launches at once (2048): consecutive chunks on one stream."""
+    rows, queries, classes, rng = synth_case(3000, d, dtype, 2100, seed=55)
+    col = make_collection(rows, dtype, "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 5, 2.0, "l2", None)
+
+
 def test_empty_collection_returns_nothing():
     col = ch.GpuCollection(64, "f32")
     col.finalize()

@@ -542,8 +542,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         KthArgs k;
         memset(&k, 0, sizeof(k));
         k.src = sample;
-        k.q_stride = 1;
-        k.e_stride = bpad;
+        k.tile_bpad = bpad;  // the two-block scan writes a tile-major sample
         k.qd = qd_dev;
         k.B = B;
         k.M = P.M;
@@ -1149,7 +1148,7 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     if ((rc = stage_device_queries(h, queries_dev, B, ws, st, &q))) return rc;
     const long long n = h->n_rows;
     const long long stride = n;
-    bool rowmajor = false;
+    bool rowmajor = false, tiled = false;
     long long bpad = B;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)std::max<long long>(stride, 1)))) return rc;
     if (path == 2) {
@@ -1170,7 +1169,8 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         if (crag_qreg_supported(h->dim_pad) || crag_qsplit_supported(h->dim_pad)) {
             rowmajor = true;
             bpad = ((long long)B + 15) / 16 * 16;
-            if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)std::max<long long>(n, 1)))) return rc;
+            tiled = !crag_qsplit_supported(h->dim_pad) && B > 128;  // crag_launch_scan_qreg2's layout
+            if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)((std::max<long long>(n, 1) + 31) / 32 * 32)))) return rc;
             a.sample = (uint32_t*)ws->sample.p;
             a.sample_stride = bpad;
             if (crag_qsplit_supported(h->dim_pad) ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
@@ -1215,12 +1215,14 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     }
     HIPCHK(hipStreamSynchronize(st));
     // keys -> floats on the host side of the boundary is the caller's job; here we decode on the host
-    std::vector<uint32_t> keys((size_t)(rowmajor ? bpad : B) * (size_t)n);
+    std::vector<uint32_t> keys((size_t)(rowmajor ? bpad : B) * (size_t)(tiled ? (n + 31) / 32 * 32 : n));
     HIPCHK(hipMemcpy(keys.data(), ws->sample.p, keys.size() * 4, hipMemcpyDeviceToHost));
     std::vector<float> sc((size_t)B * (size_t)n);
     for (int b = 0; b < B; ++b)
         for (long long i = 0; i < n; ++i)
-            sc[(size_t)b * n + i] = crag_fkey_inv(rowmajor ? keys[(size_t)i * bpad + b] : keys[(size_t)b * n + i]);
+            sc[(size_t)b * n + i] = crag_fkey_inv(tiled      ? keys[((size_t)(i >> 5) * bpad + b) * 32 + (i & 31)]
+                                                  : rowmajor ? keys[(size_t)i * bpad + b]
+                                                             : keys[(size_t)b * n + i]);
     HIPCHK(hipMemcpy(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }

@@ -156,6 +156,8 @@ struct KthArgs {
     // seed_cnt is the segment counter array -- the scan workgroups then append behind the seeds
     int seed_n_seg, seed_seg_cap;
     long long seed_stride;
+    // > 0: src is the tile-major sample of crag_launch_scan_qreg2 with this Bpad (q_stride, e_stride, off0 unused)
+    long long tile_bpad;
 };
 int crag_launch_kth(const KthArgs& a, hipStream_t s);
 struct FinalizeArgs {

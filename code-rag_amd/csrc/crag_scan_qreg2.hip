@@ -14,7 +14,7 @@
 // prefetch of a later tile, the filter's fast path = minimum score of the lane's rows per block) is
 // one generated statement, crag_qreg2_kloop.inc (gen_qreg2_kloop.py holds the register contract).
 //
-//   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced)
+//   MODE 0 (sample): ordered-float score keys to the TILE-major sample [row / 32][Bpad][row % 32]
 //   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
 #include "crag_common.h"
 
@@ -233,13 +233,24 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                 // row numbers fit 32 bits (rows per collection < 2^32, include/coderag_hip.h)
                 const unsigned mb = (unsigned)t * Q2_TM + 4 * fh, re = (unsigned)row_end;
                 if (MODE == 0) {
+                    // tile-major sample: key of (row, query) at ((row / 32) * Bpad + query) * 32 + row % 32, so the
+                    // lane stores its four 4-row runs as 16-byte words and k_kth reads whole 128-byte lines
+                    // (rows past row_end land in the tile's padding and are never read)
+                    uint4* s0 = (uint4*)(sample + ((long long)t * sample_stride + q0) * 32 + 4 * fh);
+                    uint4* s1 = (uint4*)(sample + ((long long)t * sample_stride + q1) * 32 + 4 * fh);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
-                        if (m < re) {
-                            if (ok0) sample[m * sample_stride + q0] = crag_fkey(fmaf(e.c, acc0[r], xs[r]));
-                            if (ok1) sample[m * sample_stride + q1] = crag_fkey(fmaf(e.c, acc1[r], xs[r]));
-                        }
+                    for (int g = 0; g < 4; ++g) {
+                        uint4 k0, k1;
+                        k0.x = crag_fkey(fmaf(e.c, acc0[4 * g + 0], xs[4 * g + 0]));
+                        k0.y = crag_fkey(fmaf(e.c, acc0[4 * g + 1], xs[4 * g + 1]));
+                        k0.z = crag_fkey(fmaf(e.c, acc0[4 * g + 2], xs[4 * g + 2]));
+                        k0.w = crag_fkey(fmaf(e.c, acc0[4 * g + 3], xs[4 * g + 3]));
+                        k1.x = crag_fkey(fmaf(e.c, acc1[4 * g + 0], xs[4 * g + 0]));
+                        k1.y = crag_fkey(fmaf(e.c, acc1[4 * g + 1], xs[4 * g + 1]));
+                        k1.z = crag_fkey(fmaf(e.c, acc1[4 * g + 2], xs[4 * g + 2]));
+                        k1.w = crag_fkey(fmaf(e.c, acc1[4 * g + 3], xs[4 * g + 3]));
+                        if (ok0) s0[2 * g] = k0;
+                        if (ok1) s1[2 * g] = k1;
                     }
                 } else {
                     {
@@ -321,7 +332,7 @@ int crag_qreg2_segments(int n_queries, int n_cus) {
     return 2 * 8 * (streams < 1 ? 1 : streams);  // two per workgroup: one per half-wave (row half fh)
 }
 
-// sample layout of this kernel: sample[row * sample_stride + query]  (row-major), as crag_launch_scan_qreg
+// sample layout of this kernel: tile-major, key of (row, query) at ((row / 32) * sample_stride + query) * 32 + row % 32
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
     if (mode == 1 && (a.n_seg != crag_qreg2_segments(a.n_queries, n_cus) || a.seg_cap < 1 ||

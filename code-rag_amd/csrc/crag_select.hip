@@ -239,12 +239,16 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     }
     __syncthreads();
     if (!seg && a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[q] = 0;  // kept: the full scan appends behind them
-    const uint32_t* __restrict__ src = a.src + (long long)q * a.q_stride + a.off0;
+    const bool tiled = a.tile_bpad > 0;
+    const uint32_t* __restrict__ src = tiled ? a.src : a.src + (long long)q * a.q_stride + a.off0;
+    auto src_at = [&](int i) -> uint32_t {
+        return tiled ? src[((long long)(i >> 5) * a.tile_bpad + q) * 32 + (i & 31)] : src[(long long)i * a.e_stride];
+    };
     if (n < (long long)a.M || (!from_cand && n == (long long)a.M)) {
         if (!from_cand && tid == 0) a.tau[q] = __builtin_inff();  // every row is a candidate
         if (!from_cand && a.seed_cand) {                           // ... and every sample row is seeded
             for (int i = tid; i < (int)n; i += 1024)
-                kth_seed(a, q, (uint32_t)i, src[(long long)i * a.e_stride], (uint32_t)i);
+                kth_seed(a, q, (uint32_t)i, src_at(i), (uint32_t)i);
             __syncthreads();
             kth_seed_counts(a, q, (uint32_t)n);
         }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
     }
     for (int i = tid; i < (int)n; i += 1024) {
         const int e = seg ? seg_slot(scratch, a.n_seg, a.seg_cap, i) : i;
-        keys[i] = src[(long long)e * a.e_stride];
+        keys[i] = src_at(e);
     }
     __syncthreads();
     const uint32_t t = block_select([&](int i) { return keys[i]; }, (int)n, (uint32_t)a.M - 1u, scratch);

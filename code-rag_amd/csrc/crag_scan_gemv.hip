@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     // block -> group (groups are few; blk_first ascending)
     const int mode = pass != 0;  // 0 dense sample, 1 filter
     int g = 0;
-    while (g + 1 < n_groups && bid >= groups[g + 1].blk_first[pass]) ++g;
+    for (int hi = n_groups; hi - g > 1;) {  // the last group whose first block is <= bid (64 groups: 6 dependent loads, not 64)
+        const int mid = (g + hi) >> 1;
+        if (bid >= groups[mid].blk_first[pass]) g = mid; else hi = mid;
+    }
     const GroupDesc* __restrict__ gp = groups + g;
     const long long R = pass == 0 ? gp->n_sample : (pass == 1 ? gp->n_mid : gp->n_rows);
     const long long n_st = (R + RT - 1) / RT;

@@ -302,12 +302,28 @@ def config_regimes(ch, torch, np, dev):
     steps = 10
     for _ in range(steps):
         ch.search_multi(cols, q5, 8, 2.0, texts)
+    dt_host = time.perf_counter() - t0
+    # the same with queries and their symbol hashes resident in HBM (device-buffer entry point)
+    hashes = [cols[c].symbol_hashes(texts[c]) for c in range(ncol)]
+    off = np.zeros(ncol + 1, np.int32)
+    np.cumsum([len(h) for h in hashes], out=off[1:])
+    qh = torch.from_numpy(np.concatenate(hashes).view(np.int64)).to(dev)
+    qo = torch.from_numpy(off).to(dev)
+    q5d = torch.from_numpy(q5).to(dev).to(torch.bfloat16).contiguous()
+    for _ in range(2):
+        res = ch.search_multi_device(cols, q5d, 8, 2.0, qh, qo)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ch.search_multi_device(cols, q5d, 8, 2.0, qh, qo, out=res)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     byts = ncol * nper * (d5 * 2 + 4)
     out.append({"regime": "configs[4]: 64 collections x 156250 x 1024 bf16, one query each, top-8, symbolBoost rerank "
-                          "(host-buffer entry point, PCIe included)", "queries_per_s": round(ncol * steps / dt, 2),
+                          "(one grouped GEMV launch; inputs resident in HBM)", "queries_per_s": round(ncol * steps / dt, 2),
                 "ms_per_batch": round(dt / steps * 1e3, 4), "hbm_GBps": round(byts / (dt / steps) / 1e9, 1),
-                "hbm_frac": round(byts / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)})
+                "hbm_frac": round(byts / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "host_buffer_entry_point_queries_per_s": round(ncol * steps / dt_host, 2)})
     for col in cols:
         col.close()
     return out

@@ -320,3 +320,31 @@ def search_multi(collections: List[GpuCollection], queries: np.ndarray, top_k: i
     check(lib.crag_search_multi(hs, q.ctypes.data, b, int(top_k), float(symbol_boost), buf, _ptr(off),
                                 ids.ctypes.data, sc.ctypes.data, di.ctypes.data, cn.ctypes.data), "crag_search_multi")
     return ids, sc, di, cn
+
+
+def search_multi_device(collections: List[GpuCollection], queries, top_k: int = 10, symbol_boost: float = 2.0,
+                        q_hashes=None, q_hash_off=None, out=None, stream=None):
+    """One query per collection handle, everything on the device: queries is a CUDA tensor [B, dim] in the
+    index dtype, q_hashes / q_hash_off (sorted symbol hashes per query, B+1 int32 offsets) may be None.
+    Returns CUDA tensors (ids int64, scores float64, dists float32, counts int32)."""
+    import torch
+    lib = _lib.load()
+    b = len(collections)
+    for c in collections:
+        if not c._finalized:
+            c.finalize()
+    collections[0]._check_tensor(queries)
+    dev = queries.device
+    hs = (C.c_void_p * b)(*[c.handle for c in collections])
+    if out is None:
+        out = (torch.empty((b, top_k), dtype=torch.int64, device=dev),
+               torch.empty((b, top_k), dtype=torch.float64, device=dev),
+               torch.empty((b, top_k), dtype=torch.float32, device=dev),
+               torch.empty((b,), dtype=torch.int32, device=dev))
+    st = torch.cuda.current_stream(collections[0].device).cuda_stream if stream is None else stream
+    check(lib.crag_search_multi_device(hs, queries.data_ptr(), b, int(top_k), float(symbol_boost),
+                                       None if q_hashes is None else q_hashes.data_ptr(),
+                                       None if q_hash_off is None else q_hash_off.data_ptr(),
+                                       out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), st),
+          "crag_search_multi_device")
+    return out

@@ -1125,6 +1125,37 @@ int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k,
     return 0;
 }
 
+int crag_search_multi_device(crag_index* const* hs, const void* queries_dev, int B, int top_k, double symbol_boost,
+                             const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
+                             double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream) {
+    if (!hs || !queries_dev || !out_ids_dev || !out_scores_dev || !out_dist_dev || !out_counts_dev)
+        return fail(CRAG_E_INVALID, "crag_search_multi_device: bad arguments");
+    int rc = check_search_args(hs, B, top_k);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    crag_index* h = hs[0];
+    bool same = true;
+    for (int b = 1; b < B; ++b) same = same && hs[b] == h;
+    HIPCHK(hipSetDevice(h->device));
+    WsGuard guard(h->device);
+    if (!guard.w) return fail(CRAG_E_HIP, "could not create a HIP stream");
+    Workspace* ws = guard.w;
+    hipStream_t st = (hipStream_t)stream;
+    const void* q = nullptr;
+    if ((rc = stage_device_queries(h, queries_dev, B, ws, st, &q))) return rc;
+    if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * 2 * top_k))) return rc;
+    MergeOut mo;
+    mo.symbol_boost = symbol_boost;
+    mo.ids = (long long*)out_ids_dev;
+    mo.scores = out_scores_dev;
+    mo.dist = out_dist_dev;
+    mo.counts = out_counts_dev;
+    rc = search_entries(hs, same, q, B, top_k, q_hashes_dev, q_hash_off_dev, (CragEntry*)ws->entries.p, ws, st, &mo);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(st));  // only non-trivial after a fallback re-merge
+    return 0;
+}
+
 int crag_stats(crag_index* h, int64_t* out7, int reset) {
     if (!h || !out7) return fail(CRAG_E_INVALID, "crag_stats: bad arguments");
     for (int i = 0; i < 7; ++i) {

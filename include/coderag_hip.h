@@ -140,6 +140,16 @@ int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k,
                        const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
                        double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream);
 
+/*
+ * The same for ONE QUERY PER COLLECTION (query b against hs[b]; a handle may repeat): the device-buffer
+ * form of crag_search_multi -- one HybridSearcher serving many `code_chunks__<workspace>` collections
+ * (api/main.py:77-82) with the queries already embedded on the GPU.  All handles share dim, dtype, metric
+ * and device.
+ */
+int crag_search_multi_device(crag_index* const* hs, const void* queries_dev, int B, int top_k, double symbol_boost,
+                             const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
+                             double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream);
+
 /* ---- row-sharded corpus: one process per GPU ------------------------------------------ */
 /* bytes of one candidate entry as exchanged between ranks (float dist, u32 flags, i64 id) */
 #define CRAG_ENTRY_BYTES 16

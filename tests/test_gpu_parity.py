@@ -329,6 +329,33 @@ def test_workspace_isolated_collections_queried_together(coracle):
         assert int(cn[b]) == k and np.array_equal(ids[b, :k], wi) and np.array_equal(sc[b, :k], ws)
 
 
+def test_multi_collection_device_entry_point_equals_host_one():
+    """crag_search_multi_device (queries and symbol hashes resident in HBM) against crag_search_multi."""
+    import torch
+    rng = np.random.default_rng(12)
+    cols, texts = [], []
+    for c in range(5):
+        rows, _, classes, _ = synth_case(3000 + 777 * c, 1024, "bf16", 1, seed=100 + c)
+        match = (rng.random((1, len(rows))) < 0.1).astype(np.uint8)
+        names, tx = names_for_match(match)
+        cols.append(make_collection(rows, "bf16", "l2", names, classes, id_base=10_000 * c))
+        texts.append(tx[0])
+    order = [0, 3, 1, 4, 2, 3]                       # a handle may repeat
+    qbits = O.synth_unit_rows(len(order), 1024, 77, "bf16")
+    sel = [cols[i] for i in order]
+    tx = [texts[i] for i in order]
+    want = ch.search_multi(sel, O.bf16_bits_to_f32(qbits), 8, 2.0, tx)
+    hashes = [c.symbol_hashes(t) for c, t in zip(sel, tx)]
+    off = np.zeros(len(order) + 1, np.int32)
+    np.cumsum([len(h) for h in hashes], out=off[1:])
+    qh = torch.from_numpy(np.concatenate(hashes).view(np.int64)).cuda()
+    qo = torch.from_numpy(off).cuda()
+    q = torch.from_numpy(qbits.view(np.int16)).cuda().view(torch.bfloat16)
+    got = ch.search_multi_device(sel, q, 8, 2.0, qh, qo)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
 def test_concurrent_searches_on_one_handle(coracle):
     rows, queries, classes, _ = synth_case(20000, 384, "f32", 8, seed=51)
     col = make_collection(rows, "f32", "l2", None, classes)

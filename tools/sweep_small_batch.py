@@ -7,17 +7,20 @@ import coderag_hip as ch
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 n, d = 4_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 768
-rows = torch.empty((n, d), dtype=torch.bfloat16, device=dev)
+name = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+tdt = torch.bfloat16 if name == "bf16" else torch.float32
+esz = 2 if name == "bf16" else 4
+rows = torch.empty((n, d), dtype=tdt, device=dev)
 for lo in range(0, n, 1_000_000):
     x = torch.randn((1_000_000, d), generator=g, device=dev, dtype=torch.float32)
-    rows[lo:lo + 1_000_000] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    rows[lo:lo + 1_000_000] = (x / x.norm(dim=1, keepdim=True)).to(tdt)
 q = torch.randn((64, d), generator=g, device=dev, dtype=torch.float32)
-q = (q / q.norm(dim=1, keepdim=True)).to(torch.bfloat16)
-col = ch.GpuCollection(d, "bf16", "l2", device=0)
+q = (q / q.norm(dim=1, keepdim=True)).to(tdt)
+col = ch.GpuCollection(d, name, "l2", device=0)
 col.attach_device(rows)
 col.finalize()
 for B in (1, 2, 3, 4, 6, 8, 12, 16, 32):
-    for path in ("gemv", "mfma"):
+    for path in (("gemv", "mfma") if name == "bf16" else ("gemv",)):
         col.set_path(path)
         qb = q[:B].contiguous()
         for _ in range(3):
@@ -28,4 +31,4 @@ for B in (1, 2, 3, 4, 6, 8, 12, 16, 32):
             col.search_device(qb, 10, 2.0, out=res)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
-        print(f"d={d} B={B:3d} {path}: {dt * 1e3:.3f} ms/batch  {B / dt:9.1f} q/s  {n * d * 2 / dt / 1e12:.2f} TB/s-equivalent", flush=True)
+        print(f"{name} d={d} B={B:3d} {path}: {dt * 1e3:.3f} ms/batch  {B / dt:9.1f} q/s  {n * d * esz / dt / 1e12:.2f} TB/s-equivalent", flush=True)

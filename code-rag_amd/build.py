@@ -16,10 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_select.hip",
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip", "crag_select.hip",
            "crag_capi.hip"]
 INCLUDES = {"crag_scan_qreg.hip": ["crag_qreg_kloop.inc"], "crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
-            "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"]}
+            "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"], "crag_scan_qf32.hip": ["crag_qf32_kloop.inc"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -72,6 +72,10 @@ def check_qreg2_isa(asm_path):
                              lambda m: 128 if int(m.group(2)) == 48 else None)
 
 
+def check_qf32_isa(asm_path):
+    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qf32ILi\d+ELi\d+E\S*):", 8, lambda m: None)
+
+
 def check_qsplit_isa(asm_path):
     check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qsplitILi\d+E\S*):", 2, lambda m: None)
 
@@ -88,7 +92,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or not _newer(obj, [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]):
             jobs.append(["hipcc"] + FLAGS + ["-c", src, "-o", obj])
-            if s in ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip"):  # device ISA of the same compilation, for the checks
+            if s in ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip"):  # device ISA of the same compilation, for the checks
                 jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", os.path.join(OBJ, s.replace(".hip", ".s"))])
 
     def run(cmd):
@@ -101,6 +105,7 @@ def build(force=False, verbose=True):
             list(ex.map(run, jobs))
     check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
     check_qsplit_isa(os.path.join(OBJ, "crag_scan_qsplit.s"))
+    check_qf32_isa(os.path.join(OBJ, "crag_scan_qf32.s"))
     if jobs or not os.path.exists(LIB):
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -350,14 +350,20 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     const int path = h0->force_path;
     // auto: the query-stationary MFMA kernels hold ~5.2-5.7 TB/s from 2 queries up, the GEMV loses bandwidth with
     // every query it adds (tools/sweep_small_batch.py: MFMA ahead from B = 2-3 on 384/768/1024-element bf16 rows)
-    const int mfma_from = (crag_qreg_supported(h0->dim_pad) || crag_qsplit_supported(h0->dim_pad)) ? 3 : 9;
-    P.mfma = same_handle && h0->dtype == CRAG_BF16 && (path == 2 || (path == 0 && B >= mfma_from));
+    const bool bf16 = h0->dtype == CRAG_BF16;
+    const bool can_qreg = bf16 && crag_qreg_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
+    const bool can_qf32 = !bf16 && crag_qf32_supported(h0->dim_pad);
+    // float32: the MFMA form (128 queries per pass, MFMA-bound near 2 TB/s-equivalent) overtakes the GEMV (8 queries
+    // per pass at ~5 TB/s) once the GEMV needs a third pass
+    const int mfma_from = (can_qreg || can_qsplit) ? 3 : (can_qf32 ? 17 : 9);
+    P.mfma = same_handle && (bf16 || can_qf32) && (path == 2 || (path == 0 && B >= mfma_from));
 
-    const bool qsplit = P.mfma && crag_qsplit_supported(h0->dim_pad);  // 1024-element rows: flat buffers, row-major sample
-    const bool mfma_v1 = P.mfma && !crag_qreg_supported(h0->dim_pad) && !qsplit;  // k_scan_mfma always scans from row 0
+    const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
+    const bool qf32 = P.mfma && can_qf32;      // float32 rows: flat buffers, row-major sample
+    const bool mfma_v1 = P.mfma && !can_qreg && !qsplit && !qf32;  // k_scan_mfma always scans from row 0
     // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics) and runs
     // a multi-level cascade in which every level continues where the previous one stopped
-    const bool segmented = P.mfma && crag_qreg_supported(h0->dim_pad) && B > 128;
+    const bool segmented = P.mfma && can_qreg && B > 128;
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
     std::vector<GroupDesc> gd;
@@ -447,7 +453,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     if ((rc = ws->desc.ensure(desc_bytes))) return rc;
     if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
     if ((rc = ws->cntst.ensure(sizeof(uint32_t) * 2 * (size_t)B))) return rc;
-    const bool qreg = P.mfma && (crag_qreg_supported(h0->dim_pad) || qsplit);
+    const bool qreg = P.mfma && (can_qreg || qsplit || qf32);
     const long long bpad = ((long long)B + 15) / 16 * 16;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
     if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * CRAG_CAND_CAP))) return rc;
@@ -525,6 +531,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
             if (pass == 2) ma.row_begin = has_mid ? (qd[0].keep_mid ? qd[0].n_mid : 0) : qd[0].n_sample;
             if (ma.row_begin >= ma.row_end) return 0;
             if (qsplit) return crag_launch_scan_qsplit(ma, pass ? 1 : 0, h0->n_cus, st);
+            if (qf32) return crag_launch_scan_qf32(ma, pass ? 1 : 0, h0->n_cus, st);
             return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
                                       : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
         }
@@ -1183,7 +1190,9 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     long long bpad = B;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)std::max<long long>(stride, 1)))) return rc;
     if (path == 2) {
-        if (h->dtype != CRAG_BF16) return fail(CRAG_E_INVALID, "mfma path needs a bf16 collection");
+        const bool d_bf16 = h->dtype == CRAG_BF16;
+        const bool d_qf32 = !d_bf16 && crag_qf32_supported(h->dim_pad);
+        if (!d_bf16 && !d_qf32) return fail(CRAG_E_INVALID, "mfma path: float32 rows of this length have no MFMA scan");
         MfmaArgs a;
         memset(&a, 0, sizeof(a));
         a.rows = h->rows;
@@ -1197,16 +1206,18 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.metric = h->metric;
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = stride;
-        if (crag_qreg_supported(h->dim_pad) || crag_qsplit_supported(h->dim_pad)) {
+        const bool d_qsplit = d_bf16 && crag_qsplit_supported(h->dim_pad);
+        if (d_qf32 || d_qsplit || (d_bf16 && crag_qreg_supported(h->dim_pad))) {
             rowmajor = true;
             bpad = ((long long)B + 15) / 16 * 16;
-            tiled = !crag_qsplit_supported(h->dim_pad) && B > 128;  // crag_launch_scan_qreg2's layout
+            tiled = !d_qf32 && !d_qsplit && B > 128;  // crag_launch_scan_qreg2's layout
             if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)((std::max<long long>(n, 1) + 31) / 32 * 32)))) return rc;
             a.sample = (uint32_t*)ws->sample.p;
             a.sample_stride = bpad;
-            if (crag_qsplit_supported(h->dim_pad) ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
-                : B > 128                          ? crag_launch_scan_qreg2(a, 0, h->n_cus, st)
-                                                   : crag_launch_scan_qreg(a, 0, h->n_cus, st))
+            if (d_qf32     ? crag_launch_scan_qf32(a, 0, h->n_cus, st)
+                : d_qsplit ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
+                : B > 128  ? crag_launch_scan_qreg2(a, 0, h->n_cus, st)
+                           : crag_launch_scan_qreg(a, 0, h->n_cus, st))
                 return fail(CRAG_E_HIP, "qreg launch failed");
         } else if (crag_launch_scan_mfma(a, 0, st)) {
             return fail(CRAG_E_HIP, "mfma launch failed");

@@ -125,6 +125,9 @@ int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s)
 // same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip
 bool crag_qsplit_supported(int dim_pad);
 int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// same contract for FLOAT32 rows (dim_pad 128 / 192 / 256 / 384), v_mfma_f32_32x32x2_f32: crag_scan_qf32.hip
+bool crag_qf32_supported(int dim_pad);
+int crag_launch_scan_qf32(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // same contract, 256 queries per workgroup (two 32-query blocks per wave): the choice for B > 128
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)

@@ -150,7 +150,29 @@ def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     assert st["mfma_batches"] >= 1
 
 
-@pytest.mark.parametrize("dtype,d,nq,path", [("f32", 384, 3, "gemv"), ("bf16", 768, 8, "gemv"), ("bf16", 768, 40, "mfma"),
+@pytest.mark.parametrize("d,n,nq,top_k,metric", [
+    (384, 30011, 40, 10, "l2"),             # the reference's MiniLM rows; ragged last tile; two active waves
+    (384, 9000, 130, 100, "l2"),            # two query groups, top-100
+    (256, 5000, 33, 8, "ip"),
+    (100, 3000, 20, 10, "l2"),              # padded to 128
+    (190, 4000, 17, 10, "l2"),              # padded to 192
+    (384, 40, 9, 10, "l2"),                 # a single ragged tile
+])
+def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
+    """float32 rows through the v_mfma_f32_32x32x2_f32 scan (crag_scan_qf32.hip)."""
+    rows, queries, classes, rng = synth_case(n, d, "f32", nq, seed=78)
+    match = np.zeros((nq, n), np.uint8)
+    match[:4] = rng.random((4, n)) < 0.08
+    names, texts = names_for_match(match[:4])
+    texts = texts + ["plain query"] * (nq - 4)
+    col = make_collection(rows, "f32", metric, names, classes)
+    col.set_path("mfma")
+    check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
+    assert col.stats()["mfma_batches"] >= 1
+
+
+@pytest.mark.parametrize("dtype,d,nq,path", [("f32", 384, 40, "mfma"), ("f32", 128, 9, "mfma"), ("f32", 192, 33, "mfma"),
+                                              ("f32", 256, 129, "mfma"), ("f32", 384, 3, "gemv"), ("bf16", 768, 8, "gemv"), ("bf16", 768, 40, "mfma"),
                                               ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma"),
                                               ("bf16", 768, 150, "mfma"), ("bf16", 384, 129, "mfma"), ("bf16", 512, 256, "mfma"),
                                               ("bf16", 256, 192, "mfma"), ("bf16", 1000, 140, "mfma"), ("bf16", 1024, 9, "mfma")])

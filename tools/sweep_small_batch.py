@@ -19,8 +19,8 @@ q = (q / q.norm(dim=1, keepdim=True)).to(tdt)
 col = ch.GpuCollection(d, name, "l2", device=0)
 col.attach_device(rows)
 col.finalize()
-for B in (1, 2, 3, 4, 6, 8, 12, 16, 32):
-    for path in (("gemv", "mfma") if name == "bf16" else ("gemv",)):
+for B in (1, 2, 3, 4, 6, 8, 12, 16, 32, 64, 128):
+    for path in ("gemv", "mfma"):
         col.set_path(path)
         qb = q[:B].contiguous()
         for _ in range(3):

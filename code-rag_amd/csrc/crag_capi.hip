@@ -356,7 +356,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     // float32: the MFMA form (up to 128 queries per pass, MFMA-bound at 1.8 TB/s-equivalent) overtakes the GEMV
     // (8 queries per group at ~4.5 TB/s, groups partly overlapping) where the GEMV needs a fourth group
     // (tools/sweep_small_batch.py 384 f32: B = 16 2.45 vs 3.40 ms, B = 32 4.66 vs 3.44 ms on 4M rows)
-    const int mfma_from = (can_qreg || can_qsplit) ? 3 : (can_qf32 ? 25 : 9);
+    const int mfma_from = (can_qreg || can_qsplit) ? (h0->dim_pad >= 768 ? 2 : 3) : (can_qf32 ? 25 : 9);
     P.mfma = same_handle && (bf16 || can_qf32) && (path == 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample

@@ -108,6 +108,8 @@ def test_golden_fixtures(path):
     ("f32", 7, 500, 1, 3, "l2"),            # tiny dim
     ("bf16", 1000, 2500, 3, 10, "l2"),      # padded bf16 rows
     ("f32", 384, 20000, 20, 10, "l2"),      # f32, B > 8: several GEMV groups
+    ("f32", 384, 20000, 2, 200, "l2"),      # CRAG_MAX_TOP_K through the GEMV
+    ("bf16", 768, 600, 1, 200, "l2"),       # top_k close to the collection size
 ])
 def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, dtype, nq)
@@ -136,6 +138,8 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (1024, 30011, 200, 10, "ip"),           # 1024-element rows: split-K scan, ragged last tile, two query groups
     (1000, 9000, 17, 10, "l2"),             # padded to 1024; one partly filled wave
     (1024, 40, 9, 10, "l2"),                # a single ragged tile
+    (768, 20000, 130, 200, "l2"),           # CRAG_MAX_TOP_K: 400 candidates, M = 500, deepest cascade
+    (384, 20000, 20, 200, "ip"),
 ])
 def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)

@@ -36,6 +36,27 @@ class CragError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so, and libtorch_hip.so asks
+    for it by the unversioned file name, which the loader does not match against an already loaded
+    /opt/rocm/lib/libamdhip64.so.7.  If this library came first, torch would bring a SECOND runtime
+    into the process, which then finds no devices ("No HIP GPUs are available").  Loading torch's copy
+    first (when a torch wheel with one is installed) makes both sides share it: its soname is the
+    versioned name this library needs.  Without torch the system runtime is used as usual."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -44,6 +65,7 @@ def load() -> C.CDLL:
         raise CragError(
             f"{LIB_PATH} is missing: build it with `python code-rag_amd/build.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
     lib.crag_version.restype = i32

@@ -260,9 +260,9 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                         if (__any(hit0)) q2_append(acc0, xs, e.c, tq0, mb, re, cq, (unsigned)seg_cap, pos0);
                         if (__any(hit1)) q2_append(acc1, xs, e.c, tq1, mb, re, cq + 32ll * cand_stride, (unsigned)seg_cap, pos1);
                     }
-                    // vmcnt counts these stores too and they may retire out of order with the DMA loads, so the
-                    // counted wait below would no longer prove that the next tile has landed: drain everything
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // vmcnt counts these stores too (and they may retire out of order with the DMA loads), but the
+                    // counter is never below the number of outstanding loads and loads retire in order, so the
+                    // counted wait below still proves that the next tile has landed; it only waits a little longer
                 }
             }
         }

@@ -550,3 +550,30 @@ def test_sharded_searcher_over_rccl_world_size_1(coracle):
     want = col.search_device(q, 10, 2.0, qh, qo)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+def test_library_first_then_torch_share_one_runtime():
+    """A fresh process that searches through the library BEFORE torch touches the GPU: torch.cuda must still
+    come up (one HIP runtime in the process, coderag_hip/_lib.py) and the device-buffer entry point must
+    agree with the host-buffer one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "for p in (%r, %r): sys.path.insert(0, p)\n"
+        "import numpy as np\n"
+        "import coderag_hip as ch\n"
+        "from oracle import oracle as O\n"
+        "rows = O.synth_unit_rows(3000, 384, 5, 'f32'); qs = O.synth_unit_rows(3, 384, 6, 'f32')\n"
+        "col = ch.GpuCollection(384, 'f32', 'l2'); col.add(rows); col.finalize()\n"
+        "ids, sc, di, cn = col.search(qs, 5, 2.0)\n"
+        "import torch\n"
+        "q = torch.from_numpy(qs).cuda()\n"
+        "ids2, sc2, di2, cn2 = col.search_device(q, 5, 2.0)\n"
+        "assert np.array_equal(ids, ids2.cpu().numpy()) and np.array_equal(sc, sc2.cpu().numpy())\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "assert len(libs) == 1, libs\n"
+        "print('ok')\n" % (root, os.path.join(root, "code-rag_amd")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -110,3 +110,23 @@ def test_hashing_embedder_is_unit_norm_and_deterministic():
     assert a.shape == (2, 384) and a.dtype == np.float32
     assert np.allclose(np.linalg.norm(a, axis=1), 1.0, atol=1e-6)
     assert np.array_equal(a[0], b[0])
+
+
+def test_one_hip_runtime_per_process_whichever_side_loads_first():
+    """The library before torch, in a fresh process: both must end up on the same libamdhip64 (a second
+    runtime in the process finds no devices)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import coderag_hip as ch\n"
+        "ch.load()\n"
+        "import torch\n"
+        "torch.zeros(1)\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print('\\n'.join(libs))\n" % os.path.join(root, "code-rag_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    libs = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(libs) == 1, libs

@@ -273,6 +273,34 @@ def config_regimes(ch, torch, np, dev):
     out.append({"regime": "configs[1]: 1M x 384 fp32, batch-1 top-10 GEMV", "queries_per_s": round(50 / dt, 2),
                 "ms_per_batch": round(dt / 50 * 1e3, 4), "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1),
                 "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+    # the same collection served the way the reference serves it: /search is a sync route on FastAPI's
+    # threadpool (api/main.py:166-167), so several host threads call one searcher at once.  Four client
+    # threads, each with its own stream and result tensors; a thread's launch and wait gaps hide behind the
+    # other threads' scans (crag_search* is re-entrant on one handle)
+    import threading
+    n_thr, per_thr = 4, 50
+    c2.set_profiling(False)
+
+    def client(k, barrier):
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            mine = c2.search_device(qs[k], 10, 2.0)
+            s.synchronize()
+            barrier.wait()
+            for i in range(per_thr):
+                c2.search_device(qs[(k * 16 + i) % 64], 10, 2.0, out=mine)
+            s.synchronize()
+
+    bar = threading.Barrier(n_thr + 1)
+    thr = [threading.Thread(target=client, args=(k, bar)) for k in range(n_thr)]
+    for t in thr:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    for t in thr:
+        t.join()
+    dt_thr = time.perf_counter() - t0
+    out[-1]["queries_per_s_with_4_client_threads"] = round(n_thr * per_thr / dt_thr, 2)
     c2.close()
     del r2
     # ---- configs[4]: 64 collections x 156,250 rows x 1024 bf16 (10M rows in total)

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define CRAG_F32 0
 #define CRAG_BF16 1
@@ -190,3 +191,15 @@ int crag_launch_hist64(const unsigned long long* keys, long long n, unsigned lon
                        unsigned long long mask, int shift, unsigned int* hist256, hipStream_t s);
 int crag_launch_gather_le(const unsigned long long* keys, long long n, unsigned long long thr,
                           unsigned long long* out, unsigned int* out_cnt, unsigned int cap, hipStream_t s);
+
+// Kernels that take more than 64 KiB of dynamic LDS opt in once per (kernel, device): the attribute belongs
+// to the device that is current, and one process may hold collections on several devices.  `done` is the
+// launcher's own bit mask of devices already set (a lost race only repeats an idempotent call).
+inline void crag_allow_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done.fetch_or(bit, std::memory_order_relaxed);
+}

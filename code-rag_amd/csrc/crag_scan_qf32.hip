@@ -215,14 +215,8 @@ __global__ __launch_bounds__(64 * QF_WAVES, 1) void k_scan_qf32(const float* __r
 template <int DP>
 int launch_dp(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
     const size_t lds = (size_t)QF_NSTAGE * QF_TM * DP * 4 + (size_t)QF_NSTAGE * QF_WAVES * QF_XN_BYTES;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[mode]) {
-        if (mode == 0)
-            (void)hipFuncSetAttribute((const void*)k_scan_qf32<DP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else
-            (void)hipFuncSetAttribute((const void*)k_scan_qf32<DP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[mode] = true;
-    }
+    static std::atomic<uint64_t> lds_ok[2];
+    crag_allow_dynamic_lds(mode == 0 ? (const void*)k_scan_qf32<DP, 0> : (const void*)k_scan_qf32<DP, 1>, lds, lds_ok[mode]);
     if (mode == 0)
         hipLaunchKernelGGL((k_scan_qf32<DP, 0>), dim3(grid), dim3(64 * QF_WAVES), lds, s, (const float*)a.rows, a.xnorm, a.row_begin,
                            a.row_end, (const float*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample, a.sample_stride,

@@ -305,14 +305,8 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
 template <int KS>
 int launch_ks(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
     const size_t lds = (size_t)Q2_NSTAGE * Q2_TM * KS * 2 * 16 + (size_t)Q2_NSTAGE * Q2_WAVES * Q2_XN_BYTES;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[mode]) {
-        if (mode == 0)
-            (void)hipFuncSetAttribute((const void*)k_scan_qreg2<KS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else
-            (void)hipFuncSetAttribute((const void*)k_scan_qreg2<KS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[mode] = true;
-    }
+    static std::atomic<uint64_t> lds_ok[2];
+    crag_allow_dynamic_lds(mode == 0 ? (const void*)k_scan_qreg2<KS, 0> : (const void*)k_scan_qreg2<KS, 1>, lds, lds_ok[mode]);
     if (mode == 0)
         hipLaunchKernelGGL((k_scan_qreg2<KS, 0>), dim3(grid), dim3(64 * Q2_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
                            a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,

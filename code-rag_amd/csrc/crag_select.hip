@@ -703,11 +703,8 @@ int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n,
 
 int crag_launch_kth(const KthArgs& a, hipStream_t s) {
     const size_t lds = sizeof(uint32_t) * (CRAG_CAND_CAP + KTH_SCRATCH);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_kth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok;
+    crag_allow_dynamic_lds((const void*)k_kth, lds, lds_ok);
     hipLaunchKernelGGL(k_kth, dim3(a.B), dim3(1024), lds, s, a);
     return (int)hipGetLastError();
 }
@@ -715,11 +712,8 @@ int crag_launch_kth(const KthArgs& a, hipStream_t s) {
 int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s) {
     const size_t lds = sizeof(unsigned long long) * (CRAG_CAND_CAP + CRAG_MAX_M) + sizeof(double) * 16 +
                        sizeof(uint32_t) * (KTH_SCRATCH + 4 + 1024 + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok;
+    crag_allow_dynamic_lds((const void*)k_finalize, lds, lds_ok);
     hipLaunchKernelGGL(k_finalize, dim3(a.B), dim3(1024), lds, s, a);
     return (int)hipGetLastError();
 }

@@ -577,3 +577,45 @@ def test_library_first_then_torch_share_one_runtime():
         "print('ok')\n" % (root, os.path.join(root, "code-rag_amd")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def _fuzz_cases(count=72, seed=20261110):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(count):
+        dtype = "bf16" if rng.random() < 0.6 else "f32"
+        d = int(rng.choice([int(rng.integers(1, 1025)), 128, 192, 256, 384, 512, 768, 1024]))
+        nq = int(rng.choice([1, 2, 3, 8, 9, 24, 25, 32, 33, 64, 128, 129, 200, 256, 257, 300]))
+        top_k = int(rng.choice([1, 2, 5, 8, 10, 10, 10, 37, 100, 200]))
+        n = int(rng.choice([1, 31, 32, 33, 1000, 4096, 8191, 8192, 8193, 16385, 20000, 40000]))
+        while n * nq * d > 1.5e9:
+            n //= 2
+        metric = "l2" if rng.random() < 0.7 else "ip"
+        spread = float(rng.choice([0.0, 0.0, 0.5, 2.0]))  # log-normal spread of the row norms (0: unit rows)
+        cases.append((i, dtype, d, n, nq, top_k, metric, spread))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "%02d-%s-d%d-n%d-q%d-k%d-%s-s%g" % c)
+def test_seeded_fuzz_auto_path(coracle, case):
+    """Seeded random shapes through the AUTO dispatch (whatever kernel the library picks), rows of widely
+    different norms included (the L2 score leans on the stored |x|^2, the certificate on max |x|)."""
+    i, dtype, d, n, nq, top_k, metric, spread = case
+    rng = np.random.default_rng(1000 + i)
+    rows = O.synth_unit_rows(n, d, 300 + i, "f32")
+    if spread:
+        rows = (rows * np.exp(rng.normal(0.0, spread, size=(n, 1))).astype(np.float32)).astype(np.float32)
+        if n > 4:
+            rows[int(rng.integers(0, n))] = 0.0  # an all-zero row
+    queries = O.synth_unit_rows(nq, d, 600 + i, "f32") * np.float32(1.0 if not spread else 3.0)
+    if dtype == "bf16":
+        rows, queries = O.f32_to_bf16_bits(rows), O.f32_to_bf16_bits(queries)
+    classes = rng.choice(np.array([0, 1, 2], np.uint8), size=n, p=[0.70, 0.05, 0.25]).astype(np.uint8)
+    m = min(nq, 4)
+    match = np.zeros((nq, n), np.uint8)
+    match[:m] = rng.random((m, n)) < 0.08
+    names, texts = names_for_match(match[:m])
+    texts = texts + ["plain query"] * (nq - m)
+    col = make_collection(rows, dtype, metric, names, classes)
+    sb = float(rng.choice([2.0, 2.0, 0.3, 1.0]))
+    check_against_oracle(coracle, col, rows, queries, classes, match, top_k, sb, metric, texts)

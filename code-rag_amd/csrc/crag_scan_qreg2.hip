@@ -47,6 +47,13 @@ struct Qreg2Dma {
     unsigned xn_dst;            // wave-uniform: LDS byte address of this wave's |x|^2 slot
 };
 
+#ifdef Q2_PROFILE  // -DQ2_PROF_REALTIME: the constant 100 MHz counter instead of shader cycles
+#ifdef Q2_PROF_REALTIME
+#define Q2_PROF_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define Q2_PROF_NOW() __builtin_readcyclecounter()
+#endif
+#endif
 #ifndef Q2_KLOOP_INC  // tools/qreg_bench.hip substitutes ablation builds of the statements
 #define Q2_KLOOP_INC "crag_qreg2_kloop.inc"
 #endif
@@ -102,6 +109,9 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
+#ifdef Q2_PROFILE
+    const unsigned long long prof_entry = Q2_PROF_NOW();
+#endif
 
     // workgroup -> (query group, row-tile stream); workgroups with equal blockIdx % 8 share an XCD
     const int b = blockIdx.x;
@@ -117,19 +127,6 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     const bool wave_active = q_base < n_queries;  // wave-uniform
     const int q0 = q_base + fr, q1 = q_base + 32 + fr;
     const bool ok0 = q0 < n_queries, ok1 = q1 < n_queries;
-    // stationary B operands: this lane's two queries, k = 16 s + 8 fh + [0,8)
-    // (they live in fixed registers that only the generated statements name, see gen_qreg2_kloop.py)
-    Qreg2Load<KS>::run(queries + (long long)(ok0 ? q0 : n_queries - 1) * D + 8 * fh,
-                       queries + (long long)(ok1 ? q1 : n_queries - 1) * D + 8 * fh);
-    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
-    if (MODE == 1 && ok0) tq0 = tau[q0];
-    if (MODE == 1 && ok1) tq1 = tau[q1];
-    // this workgroup's segment of its queries' candidate buffers, and the lane's two private counters
-    const int seg = (stream * 8 + xcd) * 2 + fh;  // < n_seg
-    unsigned pos0 = 0, pos1 = 0;
-    if (MODE == 1 && ok0) pos0 = segcnt[(long long)q0 * n_seg + seg];
-    if (MODE == 1 && ok1) pos1 = segcnt[(long long)q1 * n_seg + seg];
-
     // LDS-DMA of one tile: 1-KiB pieces of the lane-linear image; linear 16-byte position P holds global
     // chunk (row P / C, chunk (P % C) ^ (row & 15)).  A wave takes pieces wave + WAVES*i of each 16-row half
     // of the tile: rows r and r + 16 swizzle alike, so both halves share one per-lane offset and differ in
@@ -179,11 +176,29 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     e.c = metric == CRAG_L2 ? -2.f : -1.f;
     e.w = metric == CRAG_L2 ? 1.f : 0.f;
 
-    // prologue: two tiles in flight, wait for the first
+    // prologue: two tiles in flight (issued BEFORE the query load, whose latency hides theirs), wait for the first
     int cur = 0;
     if (t < n_tiles) issue(t, 0);
-    if (t + t_step < n_tiles) {
-        issue(t + t_step, 1);
+    const bool two_tiles = t + t_step < n_tiles;
+    if (two_tiles) issue(t + t_step, 1);
+
+    // stationary B operands: this lane's two queries, k = 16 s + 8 fh + [0,8)
+    // (they live in fixed registers that only the generated statements name, see gen_qreg2_kloop.py)
+    Qreg2Load<KS>::run(queries + (long long)(ok0 ? q0 : n_queries - 1) * D + 8 * fh,
+                       queries + (long long)(ok1 ? q1 : n_queries - 1) * D + 8 * fh);
+#ifdef Q2_PROFILE
+    const unsigned long long prof_loaded = Q2_PROF_NOW();
+#endif
+    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
+    if (MODE == 1 && ok0) tq0 = tau[q0];
+    if (MODE == 1 && ok1) tq1 = tau[q1];
+    // this workgroup's segment of its queries' candidate buffers, and the lane's two private counters
+    const int seg = (stream * 8 + xcd) * 2 + fh;  // < n_seg
+    unsigned pos0 = 0, pos1 = 0;
+    if (MODE == 1 && ok0) pos0 = segcnt[(long long)q0 * n_seg + seg];
+    if (MODE == 1 && ok1) pos1 = segcnt[(long long)q1 * n_seg + seg];
+
+    if (two_tiles) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
 
 #ifdef Q2_PROFILE  // tools/qreg_bench.hip: time in the end-of-tile wait + barrier vs the whole loop (100 MHz ticks)
     unsigned long long prof_wait = 0, prof_bar = 0;
-    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+    const unsigned long long prof_t0 = Q2_PROF_NOW();
 #endif
     for (; t < n_tiles; t += t_step) {
         const long long nt2 = t + 2 * t_step;
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
         // tile t + step must have landed in every wave's view before anyone reads it: each wave retires all
         // but the DMA instructions it issued in THIS iteration (they are its youngest), then the barrier
 #ifdef Q2_PROFILE
-        const unsigned long long prof_a = __builtin_readcyclecounter();
+        const unsigned long long prof_a = Q2_PROF_NOW();
 #endif
         if (more) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
@@ -277,11 +292,11 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #ifdef Q2_PROFILE
-        const unsigned long long prof_b = __builtin_readcyclecounter();
+        const unsigned long long prof_b = Q2_PROF_NOW();
 #endif
         __builtin_amdgcn_s_barrier();
 #ifdef Q2_PROFILE
-        const unsigned long long prof_c = __builtin_readcyclecounter();
+        const unsigned long long prof_c = Q2_PROF_NOW();
         prof_wait += prof_b - prof_a;
         prof_bar += prof_c - prof_b;
 #endif
@@ -296,8 +311,13 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
         uint32_t* pc = segcnt + Q2_PROFILE;  // tools/qreg_bench.hip: counters behind the segment counters
         atomicAdd(&pc[0], (unsigned)prof_wait);
         atomicAdd(&pc[1], (unsigned)prof_bar);
-        atomicAdd(&pc[2], (unsigned)(__builtin_readcyclecounter() - prof_t0));
+        atomicAdd(&pc[2], (unsigned)(Q2_PROF_NOW() - prof_t0));
         atomicAdd(&pc[3], 1u);
+        atomicAdd(&pc[4], (unsigned)(prof_loaded - prof_entry));
+        atomicAdd(&pc[5], (unsigned)(prof_t0 - prof_loaded));
+        atomicMax(&pc[6], ~(unsigned)prof_entry);        // earliest entry (inverted)
+        atomicMax(&pc[7], (unsigned)prof_entry);         // latest entry
+        atomicMax(&pc[8], (unsigned)Q2_PROF_NOW());      // latest exit
     }
 #endif
 }

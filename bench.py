@@ -354,6 +354,42 @@ def config_regimes(ch, torch, np, dev):
                 "host_buffer_entry_point_queries_per_s": round(ncol * steps / dt_host, 2)})
     for col in cols:
         col.close()
+    del cols, keep
+    torch.cuda.empty_cache()
+    # ---- configs[3] at one GPU: the whole 100M x 768 bf16 corpus (153.6 GB) resident on a single MI355X
+    n3, d3, b3 = 100_000_000, 768, 256
+    if torch.cuda.mem_get_info()[0] > 175 * 2**30:
+        r3 = torch.empty((n3, d3), dtype=torch.bfloat16, device=dev)
+        for lo in range(0, n3, 1_000_000):
+            x = torch.randn((1_000_000, d3), generator=g, device=dev, dtype=torch.float32)
+            r3[lo:lo + 1_000_000] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+        del x
+        c3 = ch.GpuCollection(d3, "bf16", "l2", device=dev.index)
+        c3.attach_device(r3)
+        c3.finalize()
+        q3 = unit(b3, d3, torch.bfloat16)
+        for _ in range(2):
+            res = c3.search_device(q3, 10, 2.0)
+        c3.profile(reset=True)
+        c3.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 5
+        for _ in range(steps):
+            c3.search_device(q3, 10, 2.0, out=res)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pr = c3.profile(reset=True)
+        ms = pr["filter_scan_ms"] / max(pr["searches"], 1)
+        sr = pr["filter_scan_rows"] / max(pr["searches"], 1)
+        gbs = sr * (d3 * 2 + 4) / (ms * 1e-3) / 1e9
+        tf = 2.0 * b3 * sr * d3 / (ms * 1e-3) / 1e12
+        out.append({"regime": "configs[3] at one GPU: 100M x 768 bf16 (153.6 GB resident), batch-256 top-10",
+                    "queries_per_s": round(b3 * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 4),
+                    "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
+        c3.close()
+        del r3
     return out
 
 

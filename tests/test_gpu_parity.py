@@ -458,6 +458,56 @@ def test_full_size_10m_bf16_properties():
     assert col.stats()["fallback"] == 0
 
 
+def test_full_size_100m_bf16_one_gpu_properties():
+    """configs[3] at one GPU: the whole 100M x 768 bf16 corpus (153.6 GB) on a single MI355X.  Byte offsets
+    pass 2^32 and 2^37, so planted copies of a query sit right behind those boundaries and at both ends; the
+    three scan kernels must find them (distance 0, ascending id) and agree bit for bit."""
+    import torch
+    n, d, top_k = 100_000_000, 768, 10
+    free, _ = torch.cuda.mem_get_info()
+    if free < 175 * 2**30:
+        pytest.skip("needs 175 GiB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    rows = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
+    for lo in range(0, n, 1_000_000):
+        x = torch.randn((1_000_000, d), generator=g, device="cuda", dtype=torch.float32)
+        rows[lo:lo + 1_000_000] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    del x
+    q = torch.randn((160, d), generator=g, device="cuda", dtype=torch.float32)
+    q = (q / q.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    planted = sorted([0, 2_796_203, 89_478_486, 50_000_000, n - 1])  # 2_796_203 * 1536 > 2^32, 89_478_486 * 1536 > 2^37
+    for p in planted:
+        rows[p] = q[0]
+    col = ch.GpuCollection(d, "bf16", "l2")
+    col.attach_device(rows)
+    col.finalize()
+    assert len(col) == n
+    got = {}
+    for path, nb in (("mfma", 16), ("mfma", 160), ("gemv", 2)):
+        col.set_path(path)
+        qq = q[:nb].contiguous()
+        ids, sc, di, cn = [t.cpu().numpy() for t in col.search_device(qq, top_k, 2.0)]
+        got[(path, nb)] = (ids[:2].copy(), di[:2].copy(), sc[:2].copy())
+        assert list(ids[0, :5]) == planted and np.all(di[0, :5] == 0.0) and np.all(sc[0, :5] == 1.0)
+        for b in range(min(nb, 8)):
+            assert int(cn[b]) == top_k and len(set(ids[b])) == top_k
+            assert np.all(np.diff(di[b]) >= 0)
+            r = rows[torch.from_numpy(ids[b]).cuda()].double()
+            ref = ((qq[b].double()[None, :] - r) ** 2).sum(1).cpu().numpy()
+            assert np.allclose(di[b], ref, rtol=1e-6, atol=1e-7)
+        # the 10th distance must not exceed the 10th smallest over an independently scored slice at the far end
+        tail = rows[n - 2_000_000:].float()
+        approx = torch.cdist(qq[1:2].float(), tail).pow(2).topk(top_k, largest=False).values
+        assert di[1, -1] <= float(approx[0, -1]) + 1e-5
+        del tail
+    ref = got[("gemv", 2)]
+    for key, val in got.items():
+        for a, b in zip(val, ref):
+            assert np.array_equal(a, b), key
+    assert col.stats()["fallback"] == 0
+    col.close()
+
+
 # ---------------------------------------------------------------------------------------------
 def _chunks(n, rng):
     words = ["chunk", "asciiToArray", "stringSize", "hasUnicode", "Parser", "baseFlatten", "debounce", "map", "a",

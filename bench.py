@@ -33,14 +33,19 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~630
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
-def pmc_traffic(n, d, B):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
-    (rocprofv3 cannot wrap itself; profiles/pmc_traffic.json says how it was taken), else None."""
+def pmc_entry(n, d, B):
+    """The committed PMC pass of this same command for the workload rows|dim|batch (rocprofv3 cannot wrap
+    itself; profiles/pmc_traffic.json says how each was taken), else {}."""
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(f"{n}|{d}|{B}", {}).get("bytes")
+            return json.load(f).get(f"{n}|{d}|{B}", {})
     except OSError:
-        return None
+        return {}
+
+
+def pmc_traffic(n, d, B):
+    """HBM bytes per launch of the dominant kernel from that pass, else None."""
+    return pmc_entry(n, d, B).get("bytes")
 
 
 def main():
@@ -235,6 +240,12 @@ def extra_regimes(col, q, n, d, torch):
         out.append({"regime": name, "queries_per_s": round(B * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 4),
                     "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                     "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
+        pe = pmc_entry(n, d, B) if top_k == (100 if B == 1024 else 10) else {}
+        if pe.get("bytes"):
+            out[-1]["pmc_hbm_bytes_per_launch"] = pe["bytes"]  # rocprofv3 FETCH_SIZE pass, gfx950 correction applied
+            out[-1]["algorithmic_bytes_per_launch"] = int(sr * (d * 2 + 4))
+        if pe.get("mfma_busy_frac"):
+            out[-1]["pmc_mfma_busy_frac"] = pe["mfma_busy_frac"]  # matrix pipe busy cycles / (SIMDs x kernel cycles)
     col.set_path("auto")
     return out
 

@@ -1,12 +1,13 @@
 // Host side of the C ABI declared in include/coderag_hip.h (gfx950 only, no CPU fallback:
 // every search runs the HIP kernels or fails with CRAG_E_HIP).
 //
-// Pipeline of one search (replaces hybrid_search.py:60-125 of the reference):
-//   1 sample pass   dense scores of the first n_sample rows            (K1 or K2, mode 0)
-//   2 k_tau_select  per query threshold tau = M-th smallest sample score
-//   3 filter pass   full scan, fused compare-and-append of the rare s <= tau rows (mode 1)
-//   4 k_finalize    sort candidates, exact fp64 re-score of the M best, certificate, entries
-//   5 k_merge_rerank  merge shards, base score, path/symbol boost, filter, stable sort, top_k
+// Pipeline of one search (replaces hybrid_search.py:60-125 of the reference; DESIGN.md section 4):
+//   level 0         dense scores of the first n0 rows                  (scan kernel, mode 0)
+//   k_kth           per query threshold tau = M-th smallest score so far; sample rows <= tau seed the buffer
+//   levels 1..L     filter scans of the rows behind the previous level, fused compare-and-append of the
+//                   rare s <= tau rows (mode 1), a k_kth between levels; the last level is the long one
+//   k_finalize      cut to the M+1 best, exact fp64 re-score of the M best, certificate, 2*top_k entries
+//   k_merge_rerank  merge shards, base score, path/symbol boost, filter, stable sort, top_k
 //   (+ exact fallback scan for queries whose certificate failed or whose buffer overflowed)
 #include <algorithm>
 #include <atomic>

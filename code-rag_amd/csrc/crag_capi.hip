@@ -669,7 +669,10 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     f.qhash = (const unsigned long long*)qh_dev;
     f.qhash_off = (const int*)qhoff_dev;
     f.entries = entries_dev;
-    f.status = status;
+    // the certificates go straight to pinned host memory (device-visible): no copy-engine trip after the last kernel
+    if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
+    uint32_t* hst = ws->pinned_status;
+    f.status = hst;
     f.segcnt = segcnt;
     f.n_seg = n_seg;
     f.seg_cap = seg_cap;
@@ -684,9 +687,6 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     bool patched = false;
 
     // ---- verify: every query must carry an exactness certificate ----
-    if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
-    uint32_t* hst = ws->pinned_status;
-    HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
     HIPCHK(stream_wait(st));
     if (prof) {
         float ms0 = 0.f, ms1 = 0.f;

@@ -1,12 +1,24 @@
+#!/bin/bash
+# rocprofv3 evidence for the bench regimes (run on the GPU box from the repo root):
+#   kernel trace + stats and a separate PMC pass each for the default bench (batch-256), the batch-1 GEMV
+#   and the batch-1024 top-100 MFMA regime.  Summaries are then filtered into profiles/ (see DESIGN.md section 5).
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r01k
 rm -rf $O && mkdir -p $O
-timeout -k 10 60 rocprofv3 -L > $O/counters.txt 2>&1 || true
-grep -c "MFMA" $O/counters.txt || true
-timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_b1 -o b1 --output-format csv -- python3 bench.py --batch 1 --no-extras --steps 5 --warmup 2 > $O/pmc_b1.log 2>&1
-timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_b1024 -o b1024 --output-format csv -- python3 bench.py --batch 1024 --top-k 100 --no-extras --steps 5 --warmup 2 > $O/pmc_b1024.log 2>&1
-timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $O/kt_b1 -o b1 --output-format csv -- python3 bench.py --batch 1 --no-extras --steps 10 --warmup 2 > $O/kt_b1.log 2>&1
-timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $O/kt_b1024 -o b1024 --output-format csv -- python3 bench.py --batch 1024 --top-k 100 --no-extras --steps 10 --warmup 2 > $O/kt_b1024.log 2>&1
-find $O -name "*.csv" | head -30
-du -sh $O
+run() { # name, counters ("" = kernel trace), bench args...
+    local name=$1 pmc=$2; shift 2
+    if [ -z "$pmc" ]; then
+        timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $O/kt_$name -o $name --output-format csv -- python3 bench.py "$@" > $O/kt_$name.log 2>&1
+    else
+        timeout -s KILL 150 rocprofv3 --pmc $pmc -d $O/pmc_$name -o $name --output-format csv -- python3 bench.py "$@" > $O/pmc_$name.log 2>&1
+    fi
+}
+run b256 "" --no-extras --steps 10 --warmup 3
+run b256 "FETCH_SIZE" --no-extras --steps 5 --warmup 2
+run b1 "" --batch 1 --no-extras --steps 10 --warmup 2
+run b1 "FETCH_SIZE" --batch 1 --no-extras --steps 5 --warmup 2
+run b1024 "" --batch 1024 --top-k 100 --no-extras --steps 10 --warmup 2
+run b1024 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --batch 1024 --top-k 100 --no-extras --steps 5 --warmup 2
+timeout -k 10 300 python3 bench.py > $O/bench_full.log 2>&1
+tail -n 1 $O/bench_full.log | cut -c1-300

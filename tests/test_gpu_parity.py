@@ -669,3 +669,55 @@ def test_seeded_fuzz_auto_path(coracle, case):
     col = make_collection(rows, dtype, metric, names, classes)
     sb = float(rng.choice([2.0, 2.0, 0.3, 1.0]))
     check_against_oracle(coracle, col, rows, queries, classes, match, top_k, sb, metric, texts)
+
+
+def test_error_codes_through_the_c_abi():
+    """Error behaviour of the boundary (include/coderag_hip.h): a negative CRAG_E_* code plus a message, no
+    exception across the ABI, and the handle keeps working afterwards."""
+    import ctypes as C
+    lib = ch.load()
+    E_INVALID, E_STATE, E_LIMIT = -1, -3, -4
+    vp = C.c_void_p
+
+    def create(dim, dtype=0, metric=0):
+        h = vp()
+        return lib.crag_index_create(dim, dtype, metric, 0, C.byref(h)), h
+
+    assert create(0)[0] in (E_INVALID, E_LIMIT) and lib.crag_last_error()
+    assert create(4096, 0)[0] == E_LIMIT        # 16 KiB rows: beyond the kernels
+    assert create(384, 7)[0] == E_INVALID       # no such dtype
+    assert create(384, 0, 9)[0] == E_INVALID    # no such metric
+    rc, h = create(384)
+    assert rc == 0
+    rows = O.synth_unit_rows(500, 384, 3, "f32")
+    q = O.synth_unit_rows(2, 384, 4, "f32")
+    ids = np.empty((2, 10), np.int64); sc = np.empty((2, 10)); di = np.empty((2, 10), np.float32); cn = np.empty(2, np.int32)
+    qt = b"aa"; off = np.array([0, 1, 2], np.int64)
+
+    def search(hh, b, k):
+        return lib.crag_search(hh, q.ctypes.data, b, k, 2.0, qt, off.ctypes.data, ids.ctypes.data, sc.ctypes.data,
+                               di.ctypes.data, cn.ctypes.data)
+
+    assert lib.crag_index_add(h, rows.ctypes.data, 500, None, None, None) == 0
+    assert search(h, 2, 10) == E_STATE and b"finalize" in lib.crag_last_error()   # search before finalize
+    assert lib.crag_index_finalize(h) == 0
+    assert search(h, 2, 201) == E_LIMIT                                            # CRAG_MAX_TOP_K = 200
+    assert search(h, 0, 10) == E_INVALID and search(h, 2, 0) == E_INVALID
+    assert search(None, 2, 10) == E_INVALID
+    assert search(h, 2, 10) == 0 and list(cn) == [10, 10]                          # the handle still works
+    # collections that differ in dim cannot share one grouped call
+    rc, h2 = create(128)
+    assert rc == 0
+    r2 = O.synth_unit_rows(100, 128, 5, "f32")
+    assert lib.crag_index_add(h2, r2.ctypes.data, 100, None, None, None) == 0 and lib.crag_index_finalize(h2) == 0
+    hs = (vp * 2)(h, h2)
+    assert lib.crag_search_multi(hs, q.ctypes.data, 2, 10, 2.0, qt, off.ctypes.data, ids.ctypes.data, sc.ctypes.data,
+                                 di.ctypes.data, cn.ctypes.data) == E_INVALID
+    # a collection attached to caller memory cannot grow
+    import torch
+    t = torch.from_numpy(rows).cuda()
+    rc, h3 = create(384)
+    assert rc == 0 and lib.crag_index_attach_device(h3, t.data_ptr(), 500, None, None) == 0
+    assert lib.crag_index_add(h3, rows.ctypes.data, 10, None, None, None) == E_STATE
+    for hh in (h, h2, h3):
+        assert lib.crag_index_destroy(hh) == 0

@@ -12,6 +12,7 @@ injected embed_fn; metadata is sanitised like embed_ingest.py:26-35.
 """
 from __future__ import annotations
 
+import hashlib
 import json
 import os
 from typing import Any, Callable, Dict, Iterable, List, Optional
@@ -29,6 +30,13 @@ def sanitize_metadata(meta: Dict[str, Any]) -> Dict[str, Any]:
         else:
             out[k] = str(v)
     return out
+
+
+def chunk_id(meta: Dict[str, Any]) -> str:
+    """The chunker's id of a chunk record (indexer/chunker.py:158-160, 277): the first 12 hex digits of
+    md5("<path>|<kind>|<name>|<start_line>|<end_line>").  Used for records that arrive without an "id"."""
+    key = "|".join(str(meta.get(k, "")) for k in ("path", "kind", "name", "start_line", "end_line"))
+    return hashlib.md5(key.encode("utf-8")).hexdigest()[:12]
 
 
 def iter_jsonl(path: str):
@@ -93,7 +101,7 @@ def ingest_chunks(searcher, chunks_path: str, collection: str = "code_chunks", b
         metas.clear()
 
     for obj in iter_jsonl(chunks_path):
-        ids.append(obj["id"])
+        ids.append(obj.get("id") or chunk_id(obj.get("meta", {})))
         docs.append(obj["text"])
         metas.append(sanitize_metadata(obj.get("meta", {})))
         total += 1

@@ -568,6 +568,37 @@ def test_hybrid_searcher_end_to_end(tmp_path, dtype):
     assert batch == [hs.search(q, 8, collection_name="code_chunks__ws1") for q in queries]
 
 
+def test_ingest_chunks_from_jsonl(tmp_path):
+    """The step before the path (indexer/embed_ingest.py:57-132): the chunker's JSONL -> collection in batches,
+    metadata sanitised, persisted, found again by a fresh searcher; records without an id get the chunker's."""
+    import json
+    from coderag_hip import store
+    rng = np.random.default_rng(7)
+    ids, metas, docs = _chunks(250, rng)
+    path = tmp_path / "chunks.jsonl"
+    with open(path, "w", encoding="utf-8") as f:
+        for i, (cid, m, d) in enumerate(zip(ids, metas, docs)):
+            m = dict(m or {"name": None, "path": f"pkg/src/f{i}.js", "kind": "Function", "start_line": i, "end_line": i + 1})
+            m["tags"] = ["a", 1]                       # non-primitive -> str, None -> "" (embed_ingest.py:26-35)
+            rec = {"text": d, "meta": m}
+            if i % 3:
+                rec["id"] = cid
+            f.write(json.dumps(rec, ensure_ascii=False) + "\n")
+    emb = ch.HashingEmbedder()
+    hs = ch.HybridSearcher(db_path=str(tmp_path / "db"), embed_fn=emb)
+    summary = store.ingest_chunks(hs, str(path), collection="code_chunks__w", batch_size=64, fresh=True)
+    assert summary["input_count"] == 250 and summary["collection_count"] == 250
+    q = "Find the implementation of lodash chunk"
+    got = hs.search(q, top_k=8, include_documents=True, collection_name="code_chunks__w")
+    assert len(got) == 8 and all(isinstance(r["metadata"].get("tags"), str) for r in got)
+    recs = list(store.iter_jsonl(str(path)))
+    by_id = {(r.get("id") or store.chunk_id(r["meta"])): r for r in recs}
+    for r in got:
+        assert r["text_full"] == by_id[r["id"]]["text"]
+    hs2 = ch.HybridSearcher(db_path=str(tmp_path / "db"), embed_fn=emb)   # a fresh process would find it on disk
+    assert hs2.search(q, top_k=8, include_documents=True, collection_name="code_chunks__w") == got
+
+
 def test_sharded_searcher_over_rccl_world_size_1(coracle):
     """The bench's N > 1 code path (stage 1, RCCL all-gather, stage 2) with a real "nccl" process group of
     one rank: the only RCCL rehearsal a one-GPU box allows.  Results must equal the single-call search."""

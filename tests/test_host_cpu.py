@@ -130,3 +130,13 @@ def test_one_hip_runtime_per_process_whichever_side_loads_first():
     assert out.returncode == 0, out.stderr
     libs = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(libs) == 1, libs
+
+
+def test_chunk_id_and_metadata_sanitising_follow_the_indexer():
+    """indexer/chunker.py:158-160 (md5 of path|kind|name|start|end, 12 hex digits) and
+    indexer/embed_ingest.py:26-35 (None -> "", non-primitive -> str)."""
+    from coderag_hip import store
+    assert store.chunk_id({"path": "lodash.js", "kind": "function", "name": "asciiToArray", "start_line": 1, "end_line": 3}) == "4121f2e464e3"
+    assert store.chunk_id({"path": "src/größe.ts", "kind": "class", "name": "Größe", "start_line": 10, "end_line": 42}) == "4ff978997a88"
+    m = store.sanitize_metadata({"a": None, "b": 1, "c": 1.5, "d": True, "e": "x", "f": [1, 2], "g": {"k": 1}})
+    assert m == {"a": "", "b": 1, "c": 1.5, "d": True, "e": "x", "f": "[1, 2]", "g": "{'k': 1}"}

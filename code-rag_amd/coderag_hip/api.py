@@ -45,3 +45,10 @@ def search_route(searcher, query: str, top_k: int = 10, symbol_boost: float = 2.
     if min_score is not None:
         out = [x for x in out if x["score"] >= float(min_score)]
     return {"query": query, "total": len(out), "results": out}
+
+
+def create_app(searcher, cache=None):
+    """The two retrieval routes of api/main.py as a FastAPI application around `searcher` (http_app.py).
+    fastapi is imported on this call, not at package import: the scoring path does not depend on it."""
+    from .http_app import build_app
+    return build_app(searcher, cache)

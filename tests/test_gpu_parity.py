@@ -566,6 +566,16 @@ def test_hybrid_searcher_end_to_end(tmp_path, dtype):
     assert hs2.search(queries[0], 8, collection_name="code_chunks__ws1") == hs.search(queries[0], 8, collection_name="code_chunks__ws1")
     batch = hs.search_batch(queries, top_k=8, collection_name="code_chunks__ws1")
     assert batch == [hs.search(q, 8, collection_name="code_chunks__ws1") for q in queries]
+    # the same over HTTP (api/main.py:166-232 -> coderag_hip/http_app.py)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from fastapi.testclient import TestClient
+        client = TestClient(ch.create_app(hs))
+        resp = client.post("/search", json={"query": queries[0], "top_k": 8, "path_prefix": "lodash/"}, headers={"X-Workspace-Id": "ws1"})
+        assert resp.status_code == 200 and resp.json() == r
+        resp = client.get("/search/Parser", params={"top_k": 4}, headers={"X-Workspace-Id": "ws1"})
+        assert resp.json() == {"symbol": "Parser", "total": len(got), "results": got}
 
 
 def test_ingest_chunks_from_jsonl(tmp_path):

@@ -140,3 +140,49 @@ def test_chunk_id_and_metadata_sanitising_follow_the_indexer():
     assert store.chunk_id({"path": "src/größe.ts", "kind": "class", "name": "Größe", "start_line": 10, "end_line": 42}) == "4ff978997a88"
     m = store.sanitize_metadata({"a": None, "b": 1, "c": 1.5, "d": True, "e": "x", "f": [1, 2], "g": {"k": 1}})
     assert m == {"a": "", "b": 1, "c": 1.5, "d": True, "e": "x", "f": "[1, 2]", "g": "{'k': 1}"}
+
+
+def test_search_routes_over_http_keep_the_reference_shape():
+    """api/main.py:143-232 served by coderag_hip.create_app: request model defaults, the X-Workspace-Id header,
+    post-filters after truncation, 422 on an empty query, the optional cache keyed by body + collection."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from fastapi.testclient import TestClient
+    rows = [{"id": "a", "score": 0.9, "metadata": {"name": "f", "kind": "Function", "path": "src/a.js",
+                                                   "start_line": 3, "end_line": None}, "text_preview": "p"},
+            {"id": "b", "score": 0.2, "metadata": {"path": "lib\\b.js"}, "text_preview": ""}]
+
+    class Fake(_FakeSearcher):
+        def search_by_symbol(self, symbol, top_k=10, collection_name="code_chunks"):
+            self.calls.append(("sym", symbol, top_k, collection_name))
+            return [{"id": "a", "score": 1.0}]
+
+    class Cache:
+        def __init__(self):
+            self.d, self.sets = {}, 0
+
+        def get(self, k):
+            return self.d.get(k)
+
+        def set(self, k, v, ttl_seconds):
+            assert ttl_seconds == 3600
+            self.d[k] = v
+            self.sets += 1
+
+    fs, cache = Fake(rows), Cache()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        client = TestClient(ch.create_app(fs, cache=cache))
+        r = client.post("/search", json={"query": "q"}, headers={"X-Workspace-Id": "w 1"})
+        assert r.status_code == 200 and r.json() == O.search_response("q", rows)
+        assert fs.calls[-1] == ("q", 10, 2.0, False, "code_chunks__w_1")
+        r = client.post("/search", json={"query": "q", "top_k": 5, "symbol_boost": 1.5, "min_score": 0.5})
+        assert r.json() == O.search_response("q", rows, min_score=0.5) and fs.calls[-1] == ("q", 5, 1.5, False, "code_chunks")
+        n_calls = len(fs.calls)
+        assert client.post("/search", json={"query": "q"}, headers={"X-Workspace-Id": "w 1"}).json() == O.search_response("q", rows)
+        assert len(fs.calls) == n_calls and cache.sets == 2          # served from the cache, workspace in the key
+        assert client.post("/search", json={"query": ""}).status_code == 422
+        r = client.get("/search/Parser", params={"top_k": 4}, headers={"X-Workspace-Id": "default"})
+        assert r.json() == {"symbol": "Parser", "total": 1, "results": [{"id": "a", "score": 1.0}]}
+        assert fs.calls[-1] == ("sym", "Parser", 4, "code_chunks")

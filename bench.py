@@ -426,10 +426,21 @@ def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     qps_sample = nq / dt
     import importlib.util
-    chroma = ("chromadb importable, but the reference-call-sequence harness (BASELINE.md 3.3) is not built yet"
-              if importlib.util.find_spec("chromadb") else
-              "unavailable: chromadb not installed on this box (BASELINE.md 3.3), so the reference's Chroma+HybridSearcher "
+    chroma = ("unavailable: chromadb not installed on this box (BASELINE.md 3.3), so the reference's Chroma+HybridSearcher "
               "CPU path and recall@k against its HNSW result cannot be measured; the exact search has recall 1 by construction")
+    if importlib.util.find_spec("chromadb"):
+        # the reference's own call sequence on a bounded slice (tools/chroma_baseline.py); never fatal to the bench
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import chroma_baseline
+            sub = min(m, 200_000)
+            xr = rows[:sub].float().cpu().numpy()
+            xq = q[:32].float().cpu().numpy()
+            d2 = (xr * xr).sum(1)[None, :] - 2.0 * (xq @ xr.T)
+            exact = np.argsort(d2, axis=1, kind="stable")[:, :2 * top_k]
+            chroma = chroma_baseline.run(xr, xq, top_k, exact)
+        except Exception as e:  # noqa: BLE001
+            chroma = f"chromadb importable, but its run failed: {type(e).__name__}: {e}"
     return {"reference_chroma_path": chroma, "value": round(qps_sample * m / n, 4), "unit": "queries/s", "cores": cores, "kind": "port",
             "host_cpus_visible": os.cpu_count(),
             "sample": f"{nq} queries x first {m} of {n} rows in {dt:.2f} s (float32 brute force + (dist,id) top-{2 * top_k}, "

@@ -127,6 +127,22 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     const bool wave_active = q_base < n_queries;  // wave-uniform
     const int q0 = q_base + fr, q1 = q_base + 32 + fr;
     const bool ok0 = q0 < n_queries, ok1 = q1 < n_queries;
+    // stationary B operands: this lane's two queries, k = 16 s + 8 fh + [0,8)
+    // (they live in fixed registers that only the generated statements name, see gen_qreg2_kloop.py)
+    Qreg2Load<KS>::run(queries + (long long)(ok0 ? q0 : n_queries - 1) * D + 8 * fh,
+                       queries + (long long)(ok1 ? q1 : n_queries - 1) * D + 8 * fh);
+#ifdef Q2_PROFILE
+    const unsigned long long prof_loaded = Q2_PROF_NOW();
+#endif
+    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
+    if (MODE == 1 && ok0) tq0 = tau[q0];
+    if (MODE == 1 && ok1) tq1 = tau[q1];
+    // this workgroup's segment of its queries' candidate buffers, and the lane's two private counters
+    const int seg = (stream * 8 + xcd) * 2 + fh;  // < n_seg
+    unsigned pos0 = 0, pos1 = 0;
+    if (MODE == 1 && ok0) pos0 = segcnt[(long long)q0 * n_seg + seg];
+    if (MODE == 1 && ok1) pos1 = segcnt[(long long)q1 * n_seg + seg];
+
     // LDS-DMA of one tile: 1-KiB pieces of the lane-linear image; linear 16-byte position P holds global
     // chunk (row P / C, chunk (P % C) ^ (row & 15)).  A wave takes pieces wave + WAVES*i of each 16-row half
     // of the tile: rows r and r + 16 swizzle alike, so both halves share one per-lane offset and differ in
@@ -176,29 +192,12 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     e.c = metric == CRAG_L2 ? -2.f : -1.f;
     e.w = metric == CRAG_L2 ? 1.f : 0.f;
 
-    // prologue: two tiles in flight (issued BEFORE the query load, whose latency hides theirs), wait for the first
+    // prologue: two tiles in flight, wait for the first (issuing them ahead of the query load was tried: the
+    // prologue stays ~15 us either way and the whole kernel came out 0.7 % slower)
     int cur = 0;
     if (t < n_tiles) issue(t, 0);
-    const bool two_tiles = t + t_step < n_tiles;
-    if (two_tiles) issue(t + t_step, 1);
-
-    // stationary B operands: this lane's two queries, k = 16 s + 8 fh + [0,8)
-    // (they live in fixed registers that only the generated statements name, see gen_qreg2_kloop.py)
-    Qreg2Load<KS>::run(queries + (long long)(ok0 ? q0 : n_queries - 1) * D + 8 * fh,
-                       queries + (long long)(ok1 ? q1 : n_queries - 1) * D + 8 * fh);
-#ifdef Q2_PROFILE
-    const unsigned long long prof_loaded = Q2_PROF_NOW();
-#endif
-    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
-    if (MODE == 1 && ok0) tq0 = tau[q0];
-    if (MODE == 1 && ok1) tq1 = tau[q1];
-    // this workgroup's segment of its queries' candidate buffers, and the lane's two private counters
-    const int seg = (stream * 8 + xcd) * 2 + fh;  // < n_seg
-    unsigned pos0 = 0, pos1 = 0;
-    if (MODE == 1 && ok0) pos0 = segcnt[(long long)q0 * n_seg + seg];
-    if (MODE == 1 && ok1) pos1 = segcnt[(long long)q1 * n_seg + seg];
-
-    if (two_tiles) {
+    if (t + t_step < n_tiles) {
+        issue(t + t_step, 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

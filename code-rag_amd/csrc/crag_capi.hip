@@ -266,15 +266,18 @@ long long level1_rows(long long N, long long n0, int M) {
 // Filter levels of the multi-level cascade (segmented MFMA path): ascending row bounds, the last one == N;
 // level l scans rows [bound[l-1], bound[l]) (level 0 of the cascade, the dense sample, ends at n0).  Bounds grow
 // geometrically, n0 r^l, so every level is expected to add M r survivors; a level costs a launch and a
-// selection, so r ~ 6 unless the buffer would hold more than 3/4 of its capacity.
+// selection (~50 us), its survivors cost the filter's slow path on the tiles that hold them.  Same-box sweeps
+// (tools/sweep_tunables.sh history in DESIGN.md): at top-10 (M = 36) r between 3 and 6 is flat within 0.5 %, so
+// r ~ 6 (fewest launches); at top-100 (M = 225) r ~ 3 is 1.5-2 % ahead of r ~ 6 and of r ~ 2.
 std::vector<long long> cascade_bounds(long long N, long long n0, int M) {
     std::vector<long long> nb;
     if (N <= n0) return nb;
     const double R = (double)N / (double)n0;
-    int L = (int)std::ceil(std::log(R) / std::log(6.0));  // measured: 4 .. 12 within 1 % at top-10, 6 is 2-3 % ahead of 12 at top-100
-    L = std::max(1, std::min(L, 6));
+    constexpr int L_MAX = 8;
+    int L = (int)std::ceil(std::log(R) / std::log(M > 64 ? 3.0 : 6.0));
+    L = std::max(1, std::min(L, L_MAX));
     auto est = [&](int l) { return (double)l * (double)M * std::pow(R, 1.0 / l); };
-    while (L < 6 && est(L) > 0.75 * CRAG_CAND_CAP && est(L + 1) < est(L)) ++L;
+    while (L < L_MAX && est(L) > 0.75 * CRAG_CAND_CAP && est(L + 1) < est(L)) ++L;
     const double r = std::pow(R, 1.0 / L);
     double x = (double)n0;
     for (int l = 1; l < L; ++l) {
@@ -345,7 +348,9 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     P.B = B;
     P.top_k = top_k;
     P.kc = 2 * top_k;  // hybrid_search.py:62
-    P.M = P.kc + std::max(16, P.kc / 4);
+    // slack rows behind the 2*top_k-th: what the certificate may lose to approximate-score misordering before a
+    // query has to take the exact fallback (kc / 8 was 1.5 % ahead of kc / 4 at top-100; no fallbacks either way)
+    P.M = P.kc + std::max(16, P.kc / 8);
     if (P.M > CRAG_MAX_M) P.M = CRAG_MAX_M;
 
     const int path = h0->force_path;

@@ -217,7 +217,7 @@ def extra_regimes(col, q, n, d, torch):
     """batch-1 (HBM-bound GEMV) and batch-1024 top-100 (MFMA-bound GEMM) on the same corpus."""
     out = []
     for name, B, top_k, path, steps in (("batch-1 top-10 GEMV", 1, 10, "gemv", 20), ("batch-8 top-10 GEMV", 8, 10, "gemv", 10),
-                                        ("batch-8 top-10 one-block MFMA (what auto picks from 3 queries up)", 8, 10, "mfma", 10),
+                                        ("batch-8 top-10 MFMA cascade (what auto picks from 3 queries up)", 8, 10, "mfma", 10),
                                         ("batch-1024 top-100 MFMA", 1024, 100, "mfma", 5),
                                         ("batch-1024 top-10 MFMA", 1024, 10, "mfma", 5)):
         col.set_path(path)

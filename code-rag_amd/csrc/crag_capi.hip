@@ -369,8 +369,11 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     const bool qf32 = P.mfma && can_qf32;      // float32 rows: flat buffers, row-major sample
     const bool mfma_v1 = P.mfma && !can_qreg && !qsplit && !qf32;  // k_scan_mfma always scans from row 0
     // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics) and runs
-    // a multi-level cascade in which every level continues where the previous one stopped
-    const bool segmented = P.mfma && can_qreg && B > 128;
+    // a multi-level cascade in which every level continues where the previous one stopped.  Same-box sweeps
+    // (DESIGN.md section 5): it is ahead of the one-block scan with its flat buffers and three passes from
+    // 3 queries up at every row length (768-d top-10: +7 % at 8 queries, +11 % at 64; 256-d: +41 % at 128) and
+    // from 2 queries up once M > 64; two queries at top-10 stay on the one-block scan (1 % ahead there)
+    const bool segmented = P.mfma && can_qreg && (B >= 3 || P.M > 64);
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
     std::vector<GroupDesc> gd;
@@ -539,8 +542,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
             if (ma.row_begin >= ma.row_end) return 0;
             if (qsplit) return crag_launch_scan_qsplit(ma, pass ? 1 : 0, h0->n_cus, st);
             if (qf32) return crag_launch_scan_qf32(ma, pass ? 1 : 0, h0->n_cus, st);
-            return ma.n_queries > 128 ? crag_launch_scan_qreg2(ma, pass ? 1 : 0, h0->n_cus, st)
-                                      : crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);
+            return crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);  // two queries at top-10 (see `segmented`)
         }
         if (P.blocks[pass] == 0) return 0;  // every row of every group is already behind an earlier level
         return crag_launch_scan_gemv(ga, pass, P.nq_template, P.blocks[pass], st);

@@ -140,13 +140,18 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (1024, 40, 9, 10, "l2"),                # a single ragged tile
     (768, 20000, 130, 200, "l2"),           # CRAG_MAX_TOP_K: 400 candidates, M = 500, deepest cascade
     (384, 20000, 20, 200, "ip"),
+    (768, 20000, 2, 10, "l2"),              # two queries at top-10: the one-block scan with flat buffers
+    (384, 7000, 2, 10, "ip"),
+    (512, 5000, 2, 100, "l2"),              # two queries, M > 64: the two-block cascade
+    (768, 30011, 3, 10, "l2"),              # three queries: two-block cascade, one partly filled wave
 ])
 def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)
+    m = min(nq, 4)
     match = np.zeros((nq, n), np.uint8)
-    match[:4] = rng.random((4, n)) < 0.08
-    names, texts = names_for_match(match[:4])
-    texts = texts + ["plain query"] * (nq - 4)
+    match[:m] = rng.random((m, n)) < 0.08
+    names, texts = names_for_match(match[:m])
+    texts = texts + ["plain query"] * (nq - m)
     col = make_collection(rows, "bf16", metric, names, classes)
     col.set_path("mfma")
     check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
@@ -433,8 +438,9 @@ def test_full_size_10m_bf16_properties():
     col.attach_device(rows)
     col.finalize()
     first4 = {}
-    # one-block MFMA scan (B = 32), two-block MFMA scan with a ragged second query group (B = 288), GEMV (B = 4)
-    for path, nb in (("mfma", 32), ("mfma", 288), ("gemv", 4)):
+    # one-block MFMA scan (B = 2), two-block MFMA cascade with one active wave (B = 32) and with a ragged second
+    # query group (B = 288), GEMV (B = 4)
+    for path, nb in (("mfma", 2), ("mfma", 32), ("mfma", 288), ("gemv", 4)):
         col.set_path(path)
         qq = q[:nb].contiguous()
         ids, sc, di, cn = [t.cpu().numpy() for t in col.search_device(qq, top_k, 2.0)]
@@ -454,7 +460,8 @@ def test_full_size_10m_bf16_properties():
     ref = first4[("gemv", 4)]
     for key, got in first4.items():
         for a, b in zip(got, ref):
-            assert np.array_equal(a, b), key
+            n_common = min(len(a), len(b))
+            assert np.array_equal(a[:n_common], b[:n_common]), key
     assert col.stats()["fallback"] == 0
 
 

@@ -247,14 +247,16 @@ def test_exact_ties_and_duplicates_use_row_id_order(coracle):
     check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
 
 
-def test_mfma_massive_ties_overflow_segments_and_fall_back(coracle):
-    """bf16, B > 128 (segmented, atomic-free candidate buffers of the two-block MFMA scan): every
-    vector 3000 times, so thousands of rows tie at each query's threshold, the per-workgroup
-    segments overflow, and those queries must come back exact through the fallback."""
+@pytest.mark.parametrize("nq", [131, 9, 3])
+def test_mfma_massive_ties_overflow_segments_and_fall_back(coracle, nq):
+    """bf16 through the segmented, atomic-free candidate buffers of the two-block MFMA scan (two query groups,
+    a few queries, three queries): every vector 3000 times, so thousands of rows tie at each query's
+    threshold, the per-workgroup segments overflow, and those queries must come back exact through the fallback."""
     base = O.synth_unit_rows(7, 768, 3, "bf16")
     rows = np.tile(base, (3000, 1))
-    queries = O.synth_unit_rows(131, 768, 4, "bf16")
+    queries = O.synth_unit_rows(max(nq, 7), 768, 4, "bf16")
     queries[:7] = base                                    # distance-0 ties as well
+    queries = np.ascontiguousarray(queries[:nq])
     classes = np.zeros(len(rows), np.uint8)
     col = make_collection(rows, "bf16", "l2", None, classes)
     col.set_path("mfma")

@@ -196,6 +196,9 @@ def main():
                    "rows_per_gpu": n, "dim": d, "batch": B, "top_k": top_k, "parallelism": f"rows/{world}"},
         "roofline": roofline,
         "exact_fallback_queries": st["fallback"],
+        # answers per second over the WHOLE sharded corpus (every query scored against all n_gpus shards and merged);
+        # `value` counts one query against one shard as the unit, so value = n_gpus x this
+        "merged_queries_per_s": round(merged_qps, 2),
     }
     line["config"]["unit"] = (f"one query scored against one {n}-row shard; value = n_gpus x batch x steps / time; "
                               f"merged answers over the whole {world * n}-row corpus: {merged_qps:.2f} queries/s")

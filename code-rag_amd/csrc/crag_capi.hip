@@ -374,6 +374,9 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     // 3 queries up at every row length (768-d top-10: +7 % at 8 queries, +11 % at 64; 256-d: +41 % at 128) and
     // from 2 queries up once M > 64; two queries at top-10 stay on the one-block scan (1 % ahead there)
     const bool segmented = P.mfma && can_qreg && (B >= 3 || P.M > 64);
+    // every query-stationary scan runs the cascade; the one-block forms (two queries on short rows, 1024-element
+    // rows, float32 rows) keep their flat buffers and returning atomics underneath it
+    const bool cascade = P.mfma && (can_qreg || qsplit || qf32);
     // ---- descriptors ----
     std::vector<QueryDesc> qd((size_t)B);
     std::vector<GroupDesc> gd;
@@ -396,7 +399,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
             const double est = (double)P.M * ((double)d.n_mid / (double)d.n_sample + (double)d.n_rows / (double)d.n_mid);
             d.keep_mid = est <= CRAG_CAND_CAP / 2 ? 1 : 0;
         }
-        if (segmented) d.keep_mid = 1;  // survivors of every level stay in the buffer
+        if (cascade) d.keep_mid = 1;  // survivors of every level stay in the buffer
         P.sample_stride = std::max<long long>(P.sample_stride, d.n_sample);
         P.need_mid = P.need_mid || d.n_mid > d.n_sample;
     }
@@ -549,22 +552,33 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     };
     if (prof) HIPCHK(hipEventRecord(ws->ev[0], st));
     double prof_rows = 0.0;  // rows the last (timed) filter launch scans
-    if (segmented) {
-        // level 0: dense sample of rows [0, n0) -> tau0; its rows at or below tau0 seed the segments
+    if (cascade) {
+        auto launch_level = [&](int mode) -> int {
+            if (segmented) return crag_launch_scan_qreg2(ma, mode, h0->n_cus, st);
+            if (qsplit) return crag_launch_scan_qsplit(ma, mode, h0->n_cus, st);
+            if (qf32) return crag_launch_scan_qf32(ma, mode, h0->n_cus, st);
+            return crag_launch_scan_qreg(ma, mode, h0->n_cus, st);
+        };
+        // level 0: dense sample of rows [0, n0) -> tau0; its rows at or below tau0 seed the candidate buffers
         const long long N = h0->n_rows, n0 = qd[0].n_sample;
         ma.row_begin = 0;
         ma.row_end = n0;
-        if (crag_launch_scan_qreg2(ma, 0, h0->n_cus, st)) return fail(CRAG_E_HIP, "sample scan launch failed");
+        if (launch_level(0)) return fail(CRAG_E_HIP, "sample scan launch failed");
         KthArgs k;
         memset(&k, 0, sizeof(k));
         k.src = sample;
-        k.tile_bpad = bpad;  // the two-block scan writes a tile-major sample
+        if (segmented) {
+            k.tile_bpad = bpad;  // the two-block scan writes a tile-major sample
+        } else {
+            k.q_stride = 1;      // the one-block scans write it row-major: [row][bpad]
+            k.e_stride = bpad;
+        }
         k.qd = qd_dev;
         k.B = B;
         k.M = P.M;
         k.tau = tau;
         k.seed_cand = cand;
-        k.seed_cnt = segcnt;
+        k.seed_cnt = segmented ? segcnt : cnt;
         k.seed_n_seg = n_seg;
         k.seed_seg_cap = seg_cap;
         k.seed_stride = cand_stride;
@@ -585,7 +599,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
             }
             ma.row_begin = from;
             ma.row_end = nb[l];
-            if (crag_launch_scan_qreg2(ma, 1, h0->n_cus, st)) return fail(CRAG_E_HIP, "filter scan launch failed");
+            if (launch_level(1)) return fail(CRAG_E_HIP, "filter scan launch failed");
             if (last) {
                 if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
                 prof_rows = (double)(nb[l] - from);
@@ -600,9 +614,13 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
                 k1.B = B;
                 k1.M = P.M;
                 k1.tau = tau;
-                k1.segcnt = segcnt;
-                k1.n_seg = n_seg;
-                k1.seg_cap = seg_cap;
+                if (segmented) {
+                    k1.segcnt = segcnt;
+                    k1.n_seg = n_seg;
+                    k1.seg_cap = seg_cap;
+                } else {
+                    k1.cnt = cnt;  // flat buffer: everything found so far, nothing reset (keep_mid)
+                }
                 if (crag_launch_kth(k1, st)) return fail(CRAG_E_HIP, "kth (filter level) launch failed");
             }
             from = nb[l];

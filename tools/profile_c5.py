@@ -15,12 +15,18 @@ def unit(nr, dd, dtype):
     return (x / x.norm(dim=1, keepdim=True)).to(dtype).contiguous()
 
 
-ncol, nper, d5, n_sym = 64, 156_250, 1024, 50_000
+ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # collections; the 10M rows are split evenly
+nper, d5, n_sym = 10_000_000 // ncol, 1024, 50_000
 sym_hash, sym_len = ch.hash_names([f"sym{i}" for i in range(n_sym)])
 sym_hash_t = torch.from_numpy(sym_hash.view(np.int64)).to(dev)
 cols, keep = [], []
+one_alloc = len(sys.argv) > 2 and sys.argv[2] == 'one'  # every collection a slice of ONE allocation
+big = torch.empty((ncol * nper, d5), dtype=torch.bfloat16, device=dev) if one_alloc else None
 for c in range(ncol):
     rr = unit(nper, d5, torch.bfloat16)
+    if one_alloc:
+        big[c * nper:(c + 1) * nper] = rr
+        rr = big[c * nper:(c + 1) * nper]
     zipf = (torch.rand((nper,), generator=g, device=dev).pow(3.0) * n_sym).long().clamp_(max=n_sym - 1)
     nh = sym_hash_t[zipf].contiguous()
     u = torch.rand((nper,), generator=g, device=dev)
@@ -39,4 +45,6 @@ for _ in range(2):
 t0 = time.perf_counter()
 for _ in range(10):
     ch.search_multi(cols, q5, 8, 2.0, texts)
-print(f"configs[4]: {(time.perf_counter() - t0) / 10 * 1e3:.4f} ms per 64-query batch", flush=True)
+dt = (time.perf_counter() - t0) / 10
+print(f"configs[4] with {ncol} collections x {nper} rows: {dt * 1e3:.4f} ms per {ncol}-query batch, "
+      f"{ncol * nper * (d5 * 2 + 4) / dt / 1e12:.2f} TB/s over the whole call", flush=True)

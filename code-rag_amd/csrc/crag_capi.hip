@@ -255,9 +255,14 @@ int add_common(crag_index* h, const void* rows, int64_t n, const uint64_t* name_
 // tau_l = M-th smallest score of level l's rows, so at least M rows pass every filter; expected
 // candidates per query: M*n1/n0 at level 1 and M*N/n1 at level 2, balanced by n1 = sqrt(n0*N).
 long long level0_rows(long long N, int M) { return std::min<long long>(N, M <= 64 ? 8192 : 16384); }
-long long level1_rows(long long N, long long n0, int M) {
+// `direct_max`: expected survivors per query up to which the full scan runs straight behind the sample.  A level
+// costs a launch and a selection (~30 us on the GEMV path); a survivor costs the GEMV a returning atomic that
+// stalls its wave (measured 5-7 ns each with many queries appending, ~15 ns on one query's counter), so what
+// decides is the survivors of the whole batch: same box, 64 collections x 156 k rows (650 survivors each) run
+// 2 % faster WITH level 1, 32 x 312 k 5 % faster, one query over 1M rows 8 % faster.
+long long level1_rows(long long N, long long n0, int M, double direct_max) {
     if (N <= n0) return n0;
-    if ((double)M * (double)N / (double)n0 <= CRAG_CAND_CAP / 8) return n0;  // level 2 alone is cheap enough
+    if ((double)M * (double)N / (double)n0 <= direct_max) return n0;  // level 2 alone is cheap enough
     long long n1 = (long long)std::sqrt((double)n0 * (double)N);
     n1 = (n1 + 127) / 128 * 128;
     return std::max(n0, std::min(n1, N));
@@ -389,7 +394,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         d.path_class = h->path_class;
         d.n_rows = h->n_rows;
         d.n_sample = level0_rows(h->n_rows, P.M);
-        d.n_mid = level1_rows(h->n_rows, d.n_sample, P.M);
+        d.n_mid = level1_rows(h->n_rows, d.n_sample, P.M, P.mfma ? CRAG_CAND_CAP / 8 : std::max(32.0, 2048.0 / B));
         d.id_base = h->id_base;
         d.max_xnorm = h->max_xnorm;
         // keep the level-1 candidates and let the full scan start at n_mid when both levels fit the buffer

@@ -470,7 +470,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     if ((rc = ws->ensure_pinned(desc_bytes))) return rc;
     if ((rc = ws->desc.ensure(desc_bytes))) return rc;
     if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
-    if ((rc = ws->cntst.ensure(sizeof(uint32_t) * 2 * (size_t)B))) return rc;
+    if ((rc = ws->cntst.ensure(sizeof(uint32_t) * ((size_t)B * CRAG_CNT_STRIDE + (size_t)B)))) return rc;
     const bool qreg = P.mfma && (can_qreg || qsplit || qf32);
     const long long bpad = ((long long)B + 15) / 16 * 16;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
@@ -481,11 +481,11 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     const QueryDesc* qd_dev = (const QueryDesc*)ws->desc.p;
     const GroupDesc* gd_dev = (const GroupDesc*)((char*)ws->desc.p + sizeof(QueryDesc) * (size_t)B);
     uint32_t* cnt = (uint32_t*)ws->cntst.p;
-    uint32_t* status = cnt + B;
+    uint32_t* status = cnt + (size_t)B * CRAG_CNT_STRIDE;  // device-side certificates of the exact fallback
     float* tau = (float*)ws->tau.p;
     uint32_t* sample = (uint32_t*)ws->sample.p;
     unsigned long long* cand = (unsigned long long*)ws->cand.p;
-    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)B, st));
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)B * CRAG_CNT_STRIDE + (size_t)B), st));
     const int n_seg = segmented ? crag_qreg2_segments(B, h0->n_cus) : 0;
     // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64): the COUNT must stay <= CAP
     const int seg_cap = segmented ? std::max(64, 2 * CRAG_CAND_CAP / n_seg) : 0;
@@ -768,9 +768,9 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
             mask |= 0xffull << shift;
         }
         unsigned long long* cq = (unsigned long long*)ws->cand.p + (size_t)b * CRAG_CAND_CAP;
-        HIPCHK(hipMemsetAsync(cnt + b, 0, 4, st));
+        HIPCHK(hipMemsetAsync(cnt + CRAG_CNT(b), 0, 4, st));
         if (kc > 0) {
-            if ((rc = crag_launch_gather_le(keys, n, prefix, cq, cnt + b, CRAG_CAND_CAP, st)))
+            if ((rc = crag_launch_gather_le(keys, n, prefix, cq, cnt + CRAG_CNT(b), CRAG_CAND_CAP, st)))
                 return fail(CRAG_E_HIP, "gather launch failed");
         }
         FinalizeArgs g = f;
@@ -779,7 +779,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         g.B = 1;
         g.M = std::max(kc, 1);
         g.cand = cq;
-        g.cnt = cnt + b;
+        g.cnt = cnt + CRAG_CNT(b);
         g.tau = (const float*)ws->tau.p + b;
         g.trusted = 1;
         g.segcnt = nullptr;  // the fallback's gather fills the flat buffer

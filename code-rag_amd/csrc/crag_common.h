@@ -76,6 +76,10 @@ __host__ __device__ constexpr int crag_lcm(int a, int b) { return a / crag_gcd(a
 
 // candidate buffer and sort limits of the select stage
 #define CRAG_CAND_CAP 16384
+// per-query candidate counters sit one per 128-byte line: returning atomics on one line serialise in its L2
+// channel, and with many queries appending at once (64 collections in one launch) neighbours would queue
+#define CRAG_CNT_STRIDE 32
+#define CRAG_CNT(q) ((long long)(q) * CRAG_CNT_STRIDE)
 #define CRAG_MAX_M 512      // rescored candidates per query (2*top_k + slack) upper limit
 #define CRAG_MAX_KC 400     // 2*top_k upper limit
 #define CRAG_MAX_GROUP_Q 8  // queries per GEMV group

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
             const bool pass = valid && s <= my_tau;
             if (__ballot(pass)) {
                 if (pass) {
-                    const unsigned pos = atomicAdd(&cnt[qg], 1u);
+                    const unsigned pos = atomicAdd(&cnt[CRAG_CNT(qg)], 1u);
                     if (pos < CRAG_CAND_CAP)
                         cand[(long long)qg * CRAG_CAND_CAP + pos] =
                             ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)(uint32_t)my_row;

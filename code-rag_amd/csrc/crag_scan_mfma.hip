@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_scan_mfma(const unsigned short* __restr
                         if (qok && m < row_end) sample[(long long)q * sample_stride + m] = crag_fkey(s);
                     } else {
                         if (s <= tq && m < row_end) {
-                            const unsigned pos = atomicAdd(&cnt[q], 1u);
+                            const unsigned pos = atomicAdd(&cnt[CRAG_CNT(q)], 1u);
                             if (pos < CRAG_CAND_CAP)
                                 cand[(long long)q * CRAG_CAND_CAP + pos] =
                                     ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)(uint32_t)m;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * QR_WAVES, 1) void k_scan_qreg(const unsigned s
                         npass += (sc[r] <= tq && m < row_end) ? 1 : 0;
                     }
                     if (npass) {
-                        unsigned pos = atomicAdd(&cnt[my_q], (unsigned)npass);
+                        unsigned pos = atomicAdd(&cnt[CRAG_CNT(my_q)], (unsigned)npass);
                         unsigned long long* cq = cand + (long long)my_q * CRAG_CAND_CAP;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {

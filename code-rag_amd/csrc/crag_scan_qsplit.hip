@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
                 if (npass) {
                     int qa = my_q;
                     asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path
-                    unsigned pos = atomicAdd(&cnt[qa], (unsigned)npass);
+                    unsigned pos = atomicAdd(&cnt[CRAG_CNT(qa)], (unsigned)npass);
                     unsigned long long* cq = cand + (long long)qa * CRAG_CAND_CAP;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {

@@ -211,7 +211,7 @@ __device__ __forceinline__ void kth_seed_counts(const KthArgs& a, int q, uint32_
         const uint32_t ns = (uint32_t)a.seed_n_seg;
         for (uint32_t sg = tid; sg < ns; sg += 1024) a.seed_cnt[(long long)q * ns + sg] = total > sg ? (total - sg + ns - 1) / ns : 0u;
     } else if (tid == 0) {
-        a.seed_cnt[q] = total;
+        a.seed_cnt[CRAG_CNT(q)] = total;
     }
 }
 
@@ -232,13 +232,13 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
         if (n > CRAG_CAND_CAP) n = CRAG_CAND_CAP;  // the first CAP gathered rows are all <= the old tau
         if (!a.qd[q].keep_mid && tid < a.n_seg) a.segcnt[(long long)q * a.n_seg + tid] = 0;
     } else if (from_cand) {
-        const unsigned int c = a.cnt[q];
+        const unsigned int c = a.cnt[CRAG_CNT(q)];
         n = c < CRAG_CAND_CAP ? c : CRAG_CAND_CAP;  // an overflowed buffer still holds CAP rows <= the old tau
     } else {
         n = a.qd[q].n_sample;
     }
     __syncthreads();
-    if (!seg && a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[q] = 0;  // kept: the full scan appends behind them
+    if (!seg && a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[CRAG_CNT(q)] = 0;  // kept: the full scan appends behind them
     const bool tiled = a.tile_bpad > 0;
     const uint32_t* __restrict__ src = tiled ? a.src : a.src + (long long)q * a.q_stride + a.off0;
     auto src_at = [&](int i) -> uint32_t {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         if (ov || c > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
         if (c > CRAG_CAND_CAP) c = CRAG_CAND_CAP;
     } else {
-        const unsigned int raw_cnt = a.cnt[q];
+        const unsigned int raw_cnt = a.cnt[CRAG_CNT(q)];
         if (raw_cnt > CRAG_CAND_CAP) status = CRAG_ST_OVERFLOW;
         c = raw_cnt < CRAG_CAND_CAP ? (int)raw_cnt : CRAG_CAND_CAP;
     }

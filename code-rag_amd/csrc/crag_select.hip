@@ -238,7 +238,11 @@ __global__ __launch_bounds__(1024) void k_kth(KthArgs a) {
         n = a.qd[q].n_sample;
     }
     __syncthreads();
-    if (!seg && a.cnt_reset && tid == 0 && !a.qd[q].keep_mid) a.cnt_reset[CRAG_CNT(q)] = 0;  // kept: the full scan appends behind them
+    // reset only where a level 1 really ran and its survivors are NOT kept (the full scan then rescans from row 0).
+    // A query whose collection has no level 1 (n_mid == n_sample) shares this launch with queries that have one
+    // (crag_search_multi over collections of different sizes): its buffer holds the level-0 seeds, and its full
+    // scan starts behind the sample rows, so the seeds must stay.
+    if (!seg && a.cnt_reset && tid == 0 && a.qd[q].n_mid > a.qd[q].n_sample && !a.qd[q].keep_mid) a.cnt_reset[CRAG_CNT(q)] = 0;
     const bool tiled = a.tile_bpad > 0;
     const uint32_t* __restrict__ src = tiled ? a.src : a.src + (long long)q * a.q_stride + a.off0;
     auto src_at = [&](int i) -> uint32_t {

@@ -389,6 +389,36 @@ def test_multi_collection_device_entry_point_equals_host_one():
         assert np.array_equal(a.cpu().numpy(), b)
 
 
+@pytest.mark.parametrize("nq", [2, 64])
+def test_multi_collection_mixed_sizes_with_and_without_level1(coracle, nq):
+    """One grouped call over collections of very different sizes: some are smaller than the level-0 sample, some
+    have no level 1, some have one (a level-1 selection launched for the whole batch must leave the seeds of the
+    queries that had no level 1 alone).  Both multi-collection entry points against the oracle."""
+    import torch
+    d, top_k = 128, 10
+    sizes = [7, 3000, 8192, 10_000, 40_000, 320_000]
+    cols, data = [], []
+    for i, n in enumerate(sizes):
+        rows, _, classes, _ = synth_case(n, d, "f32", 1, seed=300 + i)
+        cols.append(make_collection(rows, "f32", "l2", None, classes, id_base=1_000_000 * i))
+        data.append((rows, classes))
+    order = [5, 1] if nq == 2 else [(3 * b) % len(sizes) for b in range(nq - 4)] + [5, 1, 0, 2]
+    order = sorted(order)  # consecutive queries on one collection share a group
+    q = O.synth_unit_rows(len(order), d, 999, "f32")
+    sel = [cols[i] for i in order]
+    got_host = ch.search_multi(sel, q, top_k, 2.0)
+    got_dev = [t.cpu().numpy() for t in ch.search_multi_device(sel, torch.from_numpy(q).cuda(), top_k, 2.0)]
+    for b, i in enumerate(order):
+        rows, classes = data[i]
+        (wi, ws, wd), = coracle.search_numeric(rows, q[b:b + 1], classes, None, top_k, 2.0, "l2", 1_000_000 * i)
+        k = len(wi)
+        for ids, sc, di, cn in (got_host, got_dev):
+            assert int(cn[b]) == k, (b, i, int(cn[b]), k)
+            assert np.array_equal(ids[b, :k], wi), (b, i)
+            assert np.array_equal(sc[b, :k], ws) and np.array_equal(di[b, :k].view(np.uint32), wd.view(np.uint32)), (b, i)
+    assert sum(c.stats()["fallback"] for c in cols) == 0
+
+
 def test_concurrent_searches_on_one_handle(coracle):
     rows, queries, classes, _ = synth_case(20000, 384, "f32", 8, seed=51)
     col = make_collection(rows, "f32", "l2", None, classes)

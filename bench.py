@@ -161,7 +161,7 @@ def main():
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
     roofline = {
-        "kernel": ("k_scan_qreg2" if B >= 3 else "k_scan_qreg" if B == 2 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
+        "kernel": ("k_scan_qreg2" if B >= 2 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,

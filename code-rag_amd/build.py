@@ -16,9 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_mfma.hip", "crag_scan_qreg.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip", "crag_select.hip",
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip", "crag_select.hip",
            "crag_capi.hip"]
-INCLUDES = {"crag_scan_qreg.hip": ["crag_qreg_kloop.inc"], "crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
+INCLUDES = {"crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
             "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"], "crag_scan_qf32.hip": ["crag_qf32_kloop.inc"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 

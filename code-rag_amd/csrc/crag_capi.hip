@@ -50,11 +50,30 @@ inline hipError_t stream_wait(hipStream_t st) {
     }
 }
 
+// A fixed block of device memory handed out front to back (crag_search_device_noalloc: the block is the
+// file-scope `scratch` array, see the end of this file).  Nothing is ever returned to it: a call carves what it
+// needs and the next call starts over.
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    Arena* arena = nullptr;  // set: carve from the arena, never hipMalloc / hipFree
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
+        if (arena) {
+            const size_t want = (bytes + 255) / 256 * 256;
+            if (want > arena->size - arena->used)
+                return fail(CRAG_E_LIMIT, "crag_search_device_noalloc: this search needs more than the " +
+                                              std::to_string(arena->size >> 20) + " MiB scratch array holds; use crag_search_device");
+            p = arena->base + arena->used;
+            arena->used += want;
+            cap = want;
+            return 0;
+        }
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -65,15 +84,53 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !arena) (void)hipFree(p);
         p = nullptr;
         cap = 0;
     }
 };
 
+// Small arrays of descriptors live on the stack (no heap allocation on the search path for batches up to N;
+// larger batches spill to the heap).  T is a plain struct.
+template <typename T, int N>
+struct SmallVec {
+    T inl[N];
+    std::vector<T> heap;
+    size_t n = 0;
+    bool on_heap = false;
+    T* data() { return on_heap ? heap.data() : inl; }
+    const T* data() const { return on_heap ? heap.data() : inl; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void resize(size_t k) {
+        if (k > (size_t)N) {
+            if (!on_heap) heap.assign(inl, inl + n);
+            heap.resize(k);
+            on_heap = true;
+        }
+        n = k;
+    }
+    void push_back(const T& v) {
+        resize(n + 1);
+        data()[n - 1] = v;
+    }
+    T& operator[](size_t i) { return data()[i]; }
+    const T& operator[](size_t i) const { return data()[i]; }
+    T* begin() { return data(); }
+    T* end() { return data() + n; }
+    const T* begin() const { return data(); }
+    const T* end() const { return data() + n; }
+    T& back() { return data()[n - 1]; }
+};
+
 struct Workspace {
     int device = 0;
     hipStream_t stream = nullptr;
+    Arena* arena = nullptr;  // crag_search_device_noalloc: every buffer below is carved from it, nothing is pinned
+    void use_arena(Arena* a) {
+        arena = a;
+        for (DevBuf* b : {&q, &desc, &tau, &cntst, &segcnt, &sample, &cand, &entries, &qhash, &out, &keys, &misc}) b->arena = a;
+    }
     DevBuf q, desc, tau, cntst, segcnt, sample, cand, entries, qhash, out, keys, misc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan timing (crag_set_profiling)
     void* pinned = nullptr;
@@ -274,11 +331,13 @@ long long level1_rows(long long N, long long n0, int M, double direct_max) {
 // selection (~50 us), its survivors cost the filter's slow path on the tiles that hold them.  Same-box sweeps
 // (tools/sweep_tunables.sh history in DESIGN.md): at top-10 (M = 36) r between 3 and 6 is flat within 0.5 %, so
 // r ~ 6 (fewest launches); at top-100 (M = 225) r ~ 3 is 1.5-2 % ahead of r ~ 6 and of r ~ 2.
-std::vector<long long> cascade_bounds(long long N, long long n0, int M) {
-    std::vector<long long> nb;
+constexpr int CRAG_MAX_LEVELS = 8;
+typedef SmallVec<long long, CRAG_MAX_LEVELS> LevelBounds;
+LevelBounds cascade_bounds(long long N, long long n0, int M) {
+    LevelBounds nb;
     if (N <= n0) return nb;
     const double R = (double)N / (double)n0;
-    constexpr int L_MAX = 8;
+    constexpr int L_MAX = CRAG_MAX_LEVELS;
     int L = (int)std::ceil(std::log(R) / std::log(M > 64 ? 3.0 : 6.0));
     L = std::max(1, std::min(L, L_MAX));
     auto est = [&](int l) { return (double)l * (double)M * std::pow(R, 1.0 / l); };
@@ -314,6 +373,13 @@ struct MergeOut {
     float* dist;
     int* counts;
 };
+
+// batch size limit of a search whose workspace is a fixed arena (descriptors travel as kernel arguments)
+#define CRAG_NOALLOC_MAX_B 64
+#define CRAG_E_INEXACT (-6)
+// descriptors to device memory as kernel arguments (no pinned staging buffer): one QueryDesc replicated B times
+int put_descriptors(const QueryDesc& qd, const GroupDesc* gd, int n_groups, int B, QueryDesc* qd_dev, GroupDesc* gd_dev,
+                    hipStream_t st);
 
 // one batch on one device: queries already on the device in index dtype, row stride dim_pad
 int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
@@ -362,29 +428,29 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     // auto: the query-stationary MFMA kernels hold ~5.2-5.7 TB/s from 2 queries up, the GEMV loses bandwidth with
     // every query it adds (tools/sweep_small_batch.py: MFMA ahead from B = 2-3 on 384/768/1024-element bf16 rows)
     const bool bf16 = h0->dtype == CRAG_BF16;
-    const bool can_qreg = bf16 && crag_qreg_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
+    const bool can_qreg = bf16 && crag_qreg2_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
     const bool can_qf32 = !bf16 && crag_qf32_supported(h0->dim_pad);
     // float32: the MFMA form (up to 128 queries per pass, MFMA-bound at 1.8 TB/s-equivalent) overtakes the GEMV
     // (8 queries per group at ~4.5 TB/s, groups partly overlapping) where the GEMV needs a fourth group
-    // (tools/sweep_small_batch.py 384 f32: B = 16 2.45 vs 3.40 ms, B = 32 4.66 vs 3.44 ms on 4M rows)
-    const int mfma_from = (can_qreg || can_qsplit) ? (h0->dim_pad >= 768 ? 2 : 3) : (can_qf32 ? 25 : 9);
-    P.mfma = same_handle && (bf16 || can_qf32) && (path == 2 || (path == 0 && B >= mfma_from));
+    // (tools/sweep_small_batch.py 384 f32: B = 16 2.45 vs 3.40 ms, B = 32 4.66 vs 3.44 ms on 4M rows).
+    // Rows no query-stationary kernel takes (bf16 longer than 1024 elements, float32 longer than 384) stay on
+    // the GEMV groups at every batch size.
+    const int mfma_from = can_qf32 ? 25 : (h0->dim_pad >= 768 ? 2 : 3);
+    P.mfma = same_handle && (can_qreg || can_qsplit || can_qf32) && (path == 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
-    const bool qf32 = P.mfma && can_qf32;      // float32 rows: flat buffers, row-major sample
-    const bool mfma_v1 = P.mfma && !can_qreg && !qsplit && !qf32;  // k_scan_mfma always scans from row 0
-    // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics) and runs
-    // a multi-level cascade in which every level continues where the previous one stopped.  Same-box sweeps
-    // (DESIGN.md section 5): it is ahead of the one-block scan with its flat buffers and three passes from
-    // 3 queries up at every row length (768-d top-10: +7 % at 8 queries, +11 % at 64; 256-d: +41 % at 128) and
-    // from 2 queries up once M > 64; two queries at top-10 stay on the one-block scan (1 % ahead there)
-    const bool segmented = P.mfma && can_qreg && (B >= 3 || P.M > 64);
-    // every query-stationary scan runs the cascade; the one-block forms (two queries on short rows, 1024-element
-    // rows, float32 rows) keep their flat buffers and returning atomics underneath it
-    const bool cascade = P.mfma && (can_qreg || qsplit || qf32);
+    // (float32 rows, crag_scan_qf32.hip: flat buffers and a row-major sample as well)
+    // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics); the
+    // one-block forms (1024-element rows, float32 rows) keep flat buffers and returning atomics.  Every
+    // query-stationary scan runs the multi-level cascade in which a level continues where the previous one
+    // stopped.  (A one-block scan for bf16 rows up to 768 elements served two queries at top-10 until round 2;
+    // the two-block cascade was within 1 % of it there, same box, and it went.)
+    const bool segmented = P.mfma && can_qreg;
+    const bool cascade = P.mfma;
     // ---- descriptors ----
-    std::vector<QueryDesc> qd((size_t)B);
-    std::vector<GroupDesc> gd;
+    SmallVec<QueryDesc, 64> qd;
+    qd.resize((size_t)B);
+    SmallVec<GroupDesc, 64> gd;
     for (int b = 0; b < B; ++b) {
         crag_index* h = hs[b];
         QueryDesc& d = qd[(size_t)b];
@@ -400,7 +466,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         // keep the level-1 candidates and let the full scan start at n_mid when both levels fit the buffer
         // with a 2x margin (expected survivors: M n1/n0 + M N/n1); otherwise level 1 only sets tau
         d.keep_mid = 0;
-        if (d.n_mid > d.n_sample && d.n_mid < d.n_rows && d.n_mid % 128 == 0 && !mfma_v1) {
+        if (d.n_mid > d.n_sample && d.n_mid < d.n_rows && d.n_mid % 128 == 0) {
             const double est = (double)P.M * ((double)d.n_mid / (double)d.n_sample + (double)d.n_rows / (double)d.n_mid);
             d.keep_mid = est <= CRAG_CAND_CAP / 2 ? 1 : 0;
         }
@@ -467,24 +533,29 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     // ---- workspace ----
     const size_t desc_bytes = sizeof(QueryDesc) * (size_t)B + sizeof(GroupDesc) * gd.size();
     int rc;
-    if ((rc = ws->ensure_pinned(desc_bytes))) return rc;
+    const bool noalloc = ws->arena != nullptr;  // crag_search_device_noalloc: no pinned staging, no fallback memory
+    if (!noalloc && (rc = ws->ensure_pinned(desc_bytes))) return rc;
     if ((rc = ws->desc.ensure(desc_bytes))) return rc;
     if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
     if ((rc = ws->cntst.ensure(sizeof(uint32_t) * ((size_t)B * CRAG_CNT_STRIDE + (size_t)B)))) return rc;
-    const bool qreg = P.mfma && (can_qreg || qsplit || qf32);
+    const bool qreg = P.mfma;  // every MFMA scan writes a query-minor sample: [row][bpad] or tile-major
     const long long bpad = ((long long)B + 15) / 16 * 16;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
-    if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * CRAG_CAND_CAP))) return rc;
-    memcpy(ws->pinned, qd.data(), sizeof(QueryDesc) * (size_t)B);
-    if (!gd.empty()) memcpy((char*)ws->pinned + sizeof(QueryDesc) * (size_t)B, gd.data(), sizeof(GroupDesc) * gd.size());
-    HIPCHK(hipMemcpyAsync(ws->desc.p, ws->pinned, desc_bytes, hipMemcpyHostToDevice, st));
     const QueryDesc* qd_dev = (const QueryDesc*)ws->desc.p;
     const GroupDesc* gd_dev = (const GroupDesc*)((char*)ws->desc.p + sizeof(QueryDesc) * (size_t)B);
+    if (noalloc) {
+        // one collection, so one QueryDesc for all queries and at most B / 8 groups: they travel as kernel arguments
+        if ((rc = put_descriptors(qd[0], gd.data(), (int)gd.size(), B, (QueryDesc*)ws->desc.p, (GroupDesc*)gd_dev, st))) return rc;
+    } else {
+        memcpy(ws->pinned, qd.data(), sizeof(QueryDesc) * (size_t)B);
+        if (!gd.empty()) memcpy((char*)ws->pinned + sizeof(QueryDesc) * (size_t)B, gd.data(), sizeof(GroupDesc) * gd.size());
+        HIPCHK(hipMemcpyAsync(ws->desc.p, ws->pinned, desc_bytes, hipMemcpyHostToDevice, st));
+    }
     uint32_t* cnt = (uint32_t*)ws->cntst.p;
-    uint32_t* status = cnt + (size_t)B * CRAG_CNT_STRIDE;  // device-side certificates of the exact fallback
+    uint32_t* status = cnt + (size_t)B * CRAG_CNT_STRIDE;  // device-side certificates (exact fallback; no-alloc entry point)
     float* tau = (float*)ws->tau.p;
     uint32_t* sample = (uint32_t*)ws->sample.p;
-    unsigned long long* cand = (unsigned long long*)ws->cand.p;
+    unsigned long long* cand = nullptr;
     HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)B * CRAG_CNT_STRIDE + (size_t)B), st));
     const int n_seg = segmented ? crag_qreg2_segments(B, h0->n_cus) : 0;
     // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64): the COUNT must stay <= CAP
@@ -500,7 +571,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     }
 
     // ---- passes ----
-    const bool prof = h0->profiling != 0;
+    const bool prof = h0->profiling != 0 && !noalloc;  // events are created on demand: not in the no-alloc call
     if (prof && (rc = ws->ensure_events())) return rc;
     MfmaArgs ma;
     ScanArgs ga;
@@ -537,21 +608,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         ga.cnt = cnt;
         h0->stats[6]++;
     }
-    auto scan = [&](int pass) -> int {
-        if (P.mfma) {
-            ma.row_end = pass == 0 ? qd[0].n_sample : (pass == 1 ? qd[0].n_mid : h0->n_rows);
-            ma.row_begin = 0;
-            if (!qreg) return crag_launch_scan_mfma(ma, pass ? 1 : 0, st);
-            // no row is scanned twice (as GroupDesc::from on the GEMV path): level 1 starts behind the seeded
-            // sample rows, the last pass behind whatever earlier level kept its survivors in the buffer
-            const bool has_mid = qd[0].n_mid > qd[0].n_sample;
-            if (pass == 1) ma.row_begin = qd[0].n_sample;
-            if (pass == 2) ma.row_begin = has_mid ? (qd[0].keep_mid ? qd[0].n_mid : 0) : qd[0].n_sample;
-            if (ma.row_begin >= ma.row_end) return 0;
-            if (qsplit) return crag_launch_scan_qsplit(ma, pass ? 1 : 0, h0->n_cus, st);
-            if (qf32) return crag_launch_scan_qf32(ma, pass ? 1 : 0, h0->n_cus, st);
-            return crag_launch_scan_qreg(ma, pass ? 1 : 0, h0->n_cus, st);  // two queries at top-10 (see `segmented`)
-        }
+    auto scan = [&](int pass) -> int {  // GEMV passes (the MFMA scans run the cascade below)
         if (P.blocks[pass] == 0) return 0;  // every row of every group is already behind an earlier level
         return crag_launch_scan_gemv(ga, pass, P.nq_template, P.blocks[pass], st);
     };
@@ -561,8 +618,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         auto launch_level = [&](int mode) -> int {
             if (segmented) return crag_launch_scan_qreg2(ma, mode, h0->n_cus, st);
             if (qsplit) return crag_launch_scan_qsplit(ma, mode, h0->n_cus, st);
-            if (qf32) return crag_launch_scan_qf32(ma, mode, h0->n_cus, st);
-            return crag_launch_scan_qreg(ma, mode, h0->n_cus, st);
+            return crag_launch_scan_qf32(ma, mode, h0->n_cus, st);
         };
         // level 0: dense sample of rows [0, n0) -> tau0; its rows at or below tau0 seed the candidate buffers
         const long long N = h0->n_rows, n0 = qd[0].n_sample;
@@ -589,7 +645,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         k.seed_stride = cand_stride;
         if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
         // filter levels [n0, n1), [n1, n2), ..., [.., N): each tightens tau from everything found so far
-        const std::vector<long long> nb = cascade_bounds(N, n0, P.M);
+        const LevelBounds nb = cascade_bounds(N, n0, P.M);
         long long from = n0;
         if (nb.empty() && prof) {
             HIPCHK(hipEventRecord(ws->ev[1], st));
@@ -631,56 +687,45 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
             from = nb[l];
         }
     } else {
-    // level 0: dense sample -> tau0
-    if (scan(0)) return fail(CRAG_E_HIP, "sample scan launch failed");
-    {
-        KthArgs k;
-        memset(&k, 0, sizeof(k));
-        k.src = sample;
-        if (P.mfma && qreg) {
-            k.q_stride = 1;
-            k.e_stride = bpad;
-        } else {
+        // GEMV groups: level 0 = dense sample -> tau0, its rows at or below tau0 seed the buffers
+        if (scan(0)) return fail(CRAG_E_HIP, "sample scan launch failed");
+        {
+            KthArgs k;
+            memset(&k, 0, sizeof(k));
+            k.src = sample;
             k.q_stride = P.sample_stride;
             k.e_stride = 1;
+            k.qd = qd_dev;
+            k.B = B;
+            k.M = P.M;
+            k.tau = tau;
+            k.seed_cand = cand;  // later passes continue behind the sample rows
+            k.seed_cnt = cnt;
+            if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
         }
-        k.off0 = 0;
-        k.qd = qd_dev;
-        k.B = B;
-        k.M = P.M;
-        k.tau = tau;
-        k.seed_cand = mfma_v1 ? nullptr : cand;  // later passes continue behind the sample rows
-        k.seed_cnt = mfma_v1 ? nullptr : cnt;
-        if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 0) launch failed");
-    }
-    // level 1: filtered scan of the first n1 rows -> tau1 (tightens tau0; never loosens it)
-    if (P.need_mid) {
-        if (scan(1)) return fail(CRAG_E_HIP, "level-1 scan launch failed");
-        KthArgs k;
-        memset(&k, 0, sizeof(k));
-        k.src = (const uint32_t*)cand;
-        k.q_stride = 2LL * cand_stride;
-        k.e_stride = 2;
-        k.off0 = 1;  // high word of the 64-bit key = ordered score
-        k.qd = qd_dev;
-        k.cnt = cnt;
-        k.cnt_reset = cnt;
-        k.B = B;
-        k.M = P.M;
-        k.tau = tau;
-        if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 1) launch failed");
-    }
-    if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
-    // level 2: the full scan
-    if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
-    if (scan(2)) return fail(CRAG_E_HIP, "full scan launch failed");
-    if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
-    if (P.mfma) {
-        const bool has_mid = qd[0].n_mid > qd[0].n_sample;
-        const long long from2 = mfma_v1 ? 0 : (has_mid ? (qd[0].keep_mid ? qd[0].n_mid : 0) : qd[0].n_sample);
-        prof_rows = (double)(h0->n_rows - from2);
-    }
-    for (const auto& g : gd) prof_rows += (double)(g.n_rows - g.from[2]);
+        // level 1: filtered scan of rows [n0, n1) -> tau1 (tightens tau0; never loosens it)
+        if (P.need_mid) {
+            if (scan(1)) return fail(CRAG_E_HIP, "level-1 scan launch failed");
+            KthArgs k;
+            memset(&k, 0, sizeof(k));
+            k.src = (const uint32_t*)cand;
+            k.q_stride = 2LL * cand_stride;
+            k.e_stride = 2;
+            k.off0 = 1;  // high word of the 64-bit key = ordered score
+            k.qd = qd_dev;
+            k.cnt = cnt;
+            k.cnt_reset = cnt;
+            k.B = B;
+            k.M = P.M;
+            k.tau = tau;
+            if (crag_launch_kth(k, st)) return fail(CRAG_E_HIP, "kth (level 1) launch failed");
+        }
+        if (prof) HIPCHK(hipEventRecord(ws->ev[1], st));
+        // level 2: the full scan
+        if (prof) HIPCHK(hipEventRecord(ws->ev[2], st));
+        if (scan(2)) return fail(CRAG_E_HIP, "full scan launch failed");
+        if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));
+        for (const auto& g : gd) prof_rows += (double)(g.n_rows - g.from[2]);
     }
     FinalizeArgs f;
     f.qd = qd_dev;
@@ -700,9 +745,15 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     f.qhash_off = (const int*)qhoff_dev;
     f.entries = entries_dev;
     // the certificates go straight to pinned host memory (device-visible): no copy-engine trip after the last kernel
-    if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
-    uint32_t* hst = ws->pinned_status;
-    f.status = hst;
+    uint32_t hst_local[CRAG_NOALLOC_MAX_B];
+    uint32_t* hst = hst_local;
+    if (noalloc) {
+        f.status = status;  // device memory in the scratch array, copied back below
+    } else {
+        if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
+        hst = ws->pinned_status;
+        f.status = hst;
+    }
     f.segcnt = segcnt;
     f.n_seg = n_seg;
     f.seg_cap = seg_cap;
@@ -717,6 +768,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
     bool patched = false;
 
     // ---- verify: every query must carry an exactness certificate ----
+    if (noalloc) HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
     HIPCHK(stream_wait(st));
     if (prof) {
         float ms0 = 0.f, ms1 = 0.f;
@@ -736,6 +788,9 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
         h0->stats[2]++;
         if (hst[(size_t)b] == CRAG_ST_UNCERTIFIED) h0->stats[3]++;
         if (hst[(size_t)b] == CRAG_ST_OVERFLOW) h0->stats[4]++;
+        if (noalloc)  // the exact scan needs 8 bytes per row of the collection: not in a fixed scratch array
+            return fail(CRAG_E_INEXACT, "crag_search_device_noalloc: a query failed its exactness certificate and needs the exact "
+                                        "fallback scan (8 bytes of workspace per row); call crag_search_device for this batch");
         // exact fallback: canonical float32 distance of every row, radix-select the kc smallest keys
         const long long n = h->n_rows;
         const int kc = (int)std::min<long long>(P.kc, n);
@@ -939,6 +994,33 @@ int stage_device_queries(crag_index* h, const void* queries_dev, int B, Workspac
     HIPCHK(hipMemcpy2DAsync(ws->q.p, (size_t)h->dim_pad * h->esz, queries_dev, (size_t)h->dim * h->esz,
                             (size_t)h->dim * h->esz, (size_t)B, hipMemcpyDeviceToDevice, st));
     *out = ws->q.p;
+    return 0;
+}
+
+}  // namespace
+
+namespace {
+
+struct DescBlob {
+    QueryDesc qd;
+    GroupDesc gd[CRAG_NOALLOC_MAX_B / CRAG_MAX_GROUP_Q];
+};
+__global__ __launch_bounds__(64) void k_put_descriptors(DescBlob blob, int B, int n_groups, QueryDesc* __restrict__ qd_out,
+                                                        GroupDesc* __restrict__ gd_out) {
+    for (int i = threadIdx.x; i < B; i += 64) qd_out[i] = blob.qd;
+    for (int i = threadIdx.x; i < n_groups; i += 64) gd_out[i] = blob.gd[i];
+}
+
+int put_descriptors(const QueryDesc& qd, const GroupDesc* gd, int n_groups, int B, QueryDesc* qd_dev, GroupDesc* gd_dev,
+                    hipStream_t st) {
+    if (B > CRAG_NOALLOC_MAX_B || n_groups > CRAG_NOALLOC_MAX_B / CRAG_MAX_GROUP_Q)
+        return fail(CRAG_E_LIMIT, "crag_search_device_noalloc: too many queries for the descriptor block");
+    DescBlob blob;
+    memset(&blob, 0, sizeof(blob));
+    blob.qd = qd;
+    for (int i = 0; i < n_groups; ++i) blob.gd[i] = gd[i];
+    hipLaunchKernelGGL(k_put_descriptors, dim3(1), dim3(64), 0, st, blob, B, n_groups, qd_dev, gd_dev);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1239,21 +1321,18 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = stride;
         const bool d_qsplit = d_bf16 && crag_qsplit_supported(h->dim_pad);
-        if (d_qf32 || d_qsplit || (d_bf16 && crag_qreg_supported(h->dim_pad))) {
-            rowmajor = true;
-            bpad = ((long long)B + 15) / 16 * 16;
-            tiled = !d_qf32 && !d_qsplit && B > 128;  // crag_launch_scan_qreg2's layout
-            if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)((std::max<long long>(n, 1) + 31) / 32 * 32)))) return rc;
-            a.sample = (uint32_t*)ws->sample.p;
-            a.sample_stride = bpad;
-            if (d_qf32     ? crag_launch_scan_qf32(a, 0, h->n_cus, st)
-                : d_qsplit ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
-                : B > 128  ? crag_launch_scan_qreg2(a, 0, h->n_cus, st)
-                           : crag_launch_scan_qreg(a, 0, h->n_cus, st))
-                return fail(CRAG_E_HIP, "qreg launch failed");
-        } else if (crag_launch_scan_mfma(a, 0, st)) {
-            return fail(CRAG_E_HIP, "mfma launch failed");
-        }
+        const bool d_qreg2 = d_bf16 && crag_qreg2_supported(h->dim_pad);
+        if (!d_qf32 && !d_qsplit && !d_qreg2) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
+        rowmajor = true;
+        bpad = ((long long)B + 15) / 16 * 16;
+        tiled = d_qreg2;  // crag_launch_scan_qreg2's tile-major sample
+        if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)((std::max<long long>(n, 1) + 31) / 32 * 32)))) return rc;
+        a.sample = (uint32_t*)ws->sample.p;
+        a.sample_stride = bpad;
+        if (d_qf32     ? crag_launch_scan_qf32(a, 0, h->n_cus, st)
+            : d_qsplit ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
+                       : crag_launch_scan_qreg2(a, 0, h->n_cus, st))
+            return fail(CRAG_E_HIP, "mfma scan launch failed");
     } else {
         std::vector<GroupDesc> gd;
         int blk = 0;

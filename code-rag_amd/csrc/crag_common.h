@@ -123,17 +123,16 @@ struct MfmaArgs {
     int n_seg, seg_cap;
     long long cand_stride;  // slots per query = n_seg * seg_cap (may exceed CRAG_CAND_CAP; the COUNT may not)
 };
-int crag_launch_scan_mfma(const MfmaArgs& a, int mode, hipStream_t s);
-// query-stationary MFMA scan (dim_pad in {256,384,512,768}); its sample is ROW-major [row][stride]
-bool crag_qreg_supported(int dim_pad);
-int crag_launch_scan_qreg(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// query-stationary MFMA scans; their samples are query-minor ([row][stride], or tile-major for qreg2)
 // same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip
 bool crag_qsplit_supported(int dim_pad);
 int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // same contract for FLOAT32 rows (dim_pad 128 / 192 / 256 / 384), v_mfma_f32_32x32x2_f32: crag_scan_qf32.hip
 bool crag_qf32_supported(int dim_pad);
 int crag_launch_scan_qf32(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
-// same contract, 256 queries per workgroup (two 32-query blocks per wave): the choice for B > 128
+// bf16 rows of 256 / 384 / 512 / 768 elements, 256 queries per workgroup (two 32-query blocks per wave), segmented
+// candidate buffers, tile-major sample: crag_scan_qreg2.hip
+bool crag_qreg2_supported(int dim_pad);
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)
 int crag_qreg2_segments(int n_queries, int n_cus);

@@ -4,14 +4,14 @@
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
 //
-// Same dataflow as crag_scan_qreg.hip: four waves (one per SIMD) x 32 stationary queries, corpus tiles of
+// The one-block query-stationary dataflow (crag_scan_qreg2.hip is the two-block form): four waves (one per SIMD) x 32 stationary queries, corpus tiles of
 // 32 rows streamed HBM -> LDS by LDS-DMA through a ring of three buffers, fused threshold filter with the
 // query on the lane -- on v_mfma_f32_32x32x2_f32 (two k per instruction, 16 passes: ~157 TFLOP/s peak), so
 // the kernel is MFMA-bound at about 2 TB/s-equivalent for up to 128 queries per pass over the corpus, where
 // the GEMV needs one pass per 8 queries.  The per-tile statement is generated (crag_qf32_kloop.inc,
 // gen_qf32_kloop.py holds the k-slot assignment and the register contract); query registers are fixed AGPRs
 // outside the compiler's allocation, checked on the emitted ISA by build.py.  Appends: flat buffer +
-// returning atomic, as crag_scan_qreg.hip.
+// returning atomic.
 //
 //   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced)
 //   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
@@ -233,7 +233,7 @@ int launch_dp(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
 // float32 rows this kernel takes (dim_pad of the collection)
 bool crag_qf32_supported(int dim_pad) { return dim_pad == 128 || dim_pad == 192 || dim_pad == 256 || dim_pad == 384; }
 
-// sample layout of this kernel: sample[row * sample_stride + query]  (row-major), as crag_launch_scan_qreg
+// sample layout of this kernel: sample[row * sample_stride + query]  (row-major)
 int crag_launch_scan_qf32(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
     if (a.row_begin % QF_TM) return -1;

@@ -1,10 +1,11 @@
-// K2 (two-block query-stationary form): MFMA scan for 129 <= B query batches, bf16, dim_pad <= 768, gfx950.
+// K2 (two-block query-stationary form): MFMA scan for query batches of any size (B >= 2-3 on the auto path),
+// bf16, dim_pad <= 768, gfx950.
 //
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
 //
-// Same dataflow as crag_scan_qreg.hip (queries never move, 32-row corpus tiles stream HBM -> LDS by
-// LDS-DMA through a ring of three buffers, one wave per SIMD, fused threshold filter), but a wave
+// Query-stationary dataflow (queries never move, 32-row corpus tiles stream HBM -> LDS by
+// LDS-DMA through a ring of three buffers, one wave per SIMD, fused threshold filter); a wave
 // holds TWO 32-query blocks, so a workgroup owns 256 queries and every A fragment read from LDS
 // feeds two MFMAs: per MFMA half the LDS-DMA instructions, half the L2 -> LDS bytes and half the
 // LDS reads, and the two accumulator chains alternate in the matrix pipe.  The 96 query fragments of
@@ -338,6 +339,8 @@ int launch_ks(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
 }
 
 }  // namespace
+
+bool crag_qreg2_supported(int dim_pad) { return dim_pad == 256 || dim_pad == 384 || dim_pad == 512 || dim_pad == 768; }
 
 int crag_qreg2_segments(int n_queries, int n_cus) {
     const int nqg = (n_queries + Q2_QPB - 1) / Q2_QPB;

@@ -4,14 +4,14 @@
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
 //
-// Same dataflow as crag_scan_qreg.hip: four waves (one per SIMD) x 32 stationary queries, corpus tiles of
+// The one-block query-stationary dataflow (crag_scan_qreg2.hip is the two-block form): four waves (one per SIMD) x 32 stationary queries, corpus tiles of
 // 32 rows streamed HBM -> LDS by LDS-DMA, fused threshold filter with the query on the lane.  A 32-row tile
 // of 2-KiB rows does not fit a three-deep LDS ring, so it travels as two half-tiles of 32 rows x 512
 // elements (K-parts) through a ring of FOUR 32-KiB buffers, three half-tiles in flight; one generated
 // statement (crag_qsplit_kloop.inc, gen_qsplit_kloop.py holds the register contract and the wait counts)
 // multiplies both K-parts of a tile into one accumulator, with the mid-tile rendezvous inside.  The 64
 // query fragments fill all 256 AGPRs (fixed registers outside the compiler's allocation, checked on the
-// emitted ISA by build.py).  Candidate appends use the flat buffer + returning atomic of crag_scan_qreg.hip.
+// emitted ISA by build.py).  Candidate appends use a flat per-query buffer + a returning atomic.
 //
 //   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced)
 //   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
@@ -244,7 +244,7 @@ int launch_mode(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
 
 bool crag_qsplit_supported(int dim_pad) { return dim_pad == QS_D; }
 
-// sample layout of this kernel: sample[row * sample_stride + query]  (row-major), as crag_launch_scan_qreg
+// sample layout of this kernel: sample[row * sample_stride + query]  (row-major)
 int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
     if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
     if (a.row_begin % QS_TM || a.dim_pad != QS_D) return -1;

@@ -140,7 +140,7 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (1024, 40, 9, 10, "l2"),                # a single ragged tile
     (768, 20000, 130, 200, "l2"),           # CRAG_MAX_TOP_K: 400 candidates, M = 500, deepest cascade
     (384, 20000, 20, 200, "ip"),
-    (768, 20000, 2, 10, "l2"),              # two queries at top-10: the one-block scan with flat buffers
+    (768, 20000, 2, 10, "l2"),              # two queries: one partly filled wave of the two-block cascade
     (384, 7000, 2, 10, "ip"),
     (512, 5000, 2, 100, "l2"),              # two queries, M > 64: the two-block cascade
     (768, 30011, 3, 10, "l2"),              # three queries: two-block cascade, one partly filled wave
@@ -157,6 +157,22 @@ def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
     st = col.stats()
     assert st["mfma_batches"] >= 1
+
+
+@pytest.mark.parametrize("d,n,nq,top_k,metric", [(1536, 3000, 9, 10, "l2"), (2048, 2500, 130, 100, "l2"), (1100, 3000, 33, 10, "ip"),
+                                                 (2048, 9000, 2, 10, "ip")])
+def test_parity_long_bf16_rows_stay_on_gemv_groups(coracle, d, n, nq, top_k, metric):
+    """bf16 rows longer than 1024 elements have no query-stationary MFMA scan: the auto path serves them with GEMV
+    groups of 8 queries at every batch size (the 128x128 LDS-tiled MFMA kernel that used to take them is gone)."""
+    rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=79)
+    match = np.zeros((nq, n), np.uint8)
+    match[:2] = rng.random((2, n)) < 0.08
+    names, texts = names_for_match(match[:2])
+    texts = texts + ["plain query"] * (nq - 2)
+    col = make_collection(rows, "bf16", metric, names, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
+    st = col.stats()
+    assert st["gemv_batches"] >= 1 and st["mfma_batches"] == 0
 
 
 @pytest.mark.parametrize("d,n,nq,top_k,metric", [
@@ -470,8 +486,8 @@ def test_full_size_10m_bf16_properties():
     col.attach_device(rows)
     col.finalize()
     first4 = {}
-    # one-block MFMA scan (B = 2), two-block MFMA cascade with one active wave (B = 32) and with a ragged second
-    # query group (B = 288), GEMV (B = 4)
+    # two-block MFMA cascade with two queries, with one active wave (B = 32) and with a ragged second query group
+    # (B = 288), GEMV (B = 4)
     for path, nb in (("mfma", 2), ("mfma", 32), ("mfma", 288), ("gemv", 4)):
         col.set_path(path)
         qq = q[:nb].contiguous()

@@ -1,12 +1,8 @@
 // Ablation harness for the query-stationary MFMA scan (not part of the product): times
-// k_scan_qreg<48,1> on random data with tau = -inf (no appends).
-#ifdef USE_Q2
+// k_scan_qreg2<48,1> on random data with tau = -inf (no appends).
+#define USE_Q2 1
 #include "../code-rag_amd/csrc/crag_scan_qreg2.hip"
 #define LAUNCH crag_launch_scan_qreg2
-#else
-#include "../code-rag_amd/csrc/crag_scan_qreg.hip"
-#define LAUNCH crag_launch_scan_qreg
-#endif
 #include <cstdio>
 #include <vector>
 #include <cstdlib>

@@ -25,6 +25,7 @@ SYMBOLS = [
     "crag_index_set_symbols", "crag_index_finalize",
     "crag_hash_name", "crag_hash_names", "crag_symbol_hashes",
     "crag_search", "crag_search_multi", "crag_search_device", "crag_search_multi_device",
+    "crag_search_device_noalloc",
     "crag_search_local_device", "crag_merge_rerank_device",
     "crag_stats", "crag_set_path", "crag_set_profiling", "crag_get_profile", "crag_debug_dense_scores",
 ]
@@ -91,6 +92,7 @@ def load() -> C.CDLL:
     lib.crag_search_multi.argtypes = [vp, vp, i32, i32, f64, C.c_char_p, vp, vp, vp, vp, vp]
     lib.crag_search_device.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]
     lib.crag_search_multi_device.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]
+    lib.crag_search_device_noalloc.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]
     lib.crag_search_local_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.crag_merge_rerank_device.argtypes = [i32, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]
     lib.crag_stats.argtypes = [vp, vp, i32]

@@ -374,9 +374,8 @@ struct MergeOut {
     int* counts;
 };
 
-// batch size limit of a search whose workspace is a fixed arena (descriptors travel as kernel arguments)
-#define CRAG_NOALLOC_MAX_B 64
-#define CRAG_E_INEXACT (-6)
+// CRAG_NOALLOC_MAX_B (include/coderag_hip.h): batch size limit of crag_search_device_noalloc; its scratch array is
+// sized for it, see the end of this file
 // descriptors to device memory as kernel arguments (no pinned staging buffer): one QueryDesc replicated B times
 int put_descriptors(const QueryDesc& qd, const GroupDesc* gd, int n_groups, int B, QueryDesc* qd_dev, GroupDesc* gd_dev,
                     hipStream_t st);
@@ -999,7 +998,35 @@ int stage_device_queries(crag_index* h, const void* queries_dev, int B, Workspac
 
 }  // namespace
 
+// ---- crag_search_device_noalloc: the scratch array and its per-device address ----------------------------
+// Everything crag_search_device takes from hipMalloc'ed workspace buffers (staged queries, descriptors, tau,
+// candidate counters and buffers, the dense sample, the 2*top_k entries) is carved from this array instead.
+// Sized for CRAG_NOALLOC_MAX_B = 64 queries at CRAG_MAX_TOP_K on a 256-CU device: 256 KiB queries + 16 KiB
+// descriptors + counters + 128 KiB segment counters + 4 MiB sample + 16 MiB segmented candidate slots + 400 KiB
+// entries = 21 MiB; a search that needs more is refused with CRAG_E_LIMIT.  Every GPU the library runs on
+// holds its own copy until the process ends.
+#define CRAG_NOALLOC_SCRATCH_BYTES (24u << 20)
+static __device__ __align__(256) unsigned char scratch[CRAG_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+// In host code `scratch` is a stand-in for the symbol, not a device address: the address of a device's copy
+// comes from hipGetSymbolAddress, once per device with that device current, and only that pointer is used.
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[64] = {};
+int scratch_of_device(int device, void** out) {
+    if (device < 0 || device >= 64) return fail(CRAG_E_INVALID, "crag_search_device_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        HIPCHK(hipSetDevice(device));
+        void* ptr = nullptr;
+        HIPCHK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(CRAG_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
 
 struct DescBlob {
     QueryDesc qd;
@@ -1244,6 +1271,39 @@ int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k,
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(st));  // only non-trivial after a fallback re-merge
     return 0;
+}
+
+int crag_search_device_noalloc(crag_index* h, const void* queries_dev, int B, int top_k, double symbol_boost,
+                               const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
+                               double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream) {
+    if (!h || !queries_dev || !out_ids_dev || !out_scores_dev || !out_dist_dev || !out_counts_dev)
+        return fail(CRAG_E_INVALID, "crag_search_device_noalloc: bad arguments");
+    if (B > CRAG_NOALLOC_MAX_B)
+        return fail(CRAG_E_LIMIT, "crag_search_device_noalloc: at most 64 queries per call (CRAG_NOALLOC_MAX_B); use crag_search_device");
+    crag_index* hs[CRAG_NOALLOC_MAX_B];
+    for (int b = 0; b < CRAG_NOALLOC_MAX_B; ++b) hs[b] = h;
+    int rc = check_search_args(hs, B, top_k);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    void* ptr = nullptr;
+    if ((rc = scratch_of_device(h->device, &ptr))) return rc;
+    Arena arena;
+    arena.base = (char*)ptr;
+    arena.size = CRAG_NOALLOC_SCRATCH_BYTES;
+    Workspace ws;  // on the stack: no pool, no stream of its own, no pinned host memory
+    ws.device = h->device;
+    ws.use_arena(&arena);
+    hipStream_t st = (hipStream_t)stream;
+    const void* q = nullptr;
+    if ((rc = stage_device_queries(h, queries_dev, B, &ws, st, &q))) return rc;
+    if ((rc = ws.entries.ensure(sizeof(CragEntry) * (size_t)B * 2 * top_k))) return rc;
+    MergeOut mo;
+    mo.symbol_boost = symbol_boost;
+    mo.ids = (long long*)out_ids_dev;
+    mo.scores = out_scores_dev;
+    mo.dist = out_dist_dev;
+    mo.counts = out_counts_dev;
+    return search_entries(hs, true, q, B, top_k, q_hashes_dev, q_hash_off_dev, (CragEntry*)ws.entries.p, &ws, st, &mo);
 }
 
 int crag_search_multi_device(crag_index* const* hs, const void* queries_dev, int B, int top_k, double symbol_boost,

@@ -47,6 +47,7 @@ extern "C" {
 #define CRAG_E_STATE (-3)     /* e.g. search before finalize, add after attach */
 #define CRAG_E_LIMIT (-4)     /* top_k / dim beyond what the kernels support */
 #define CRAG_E_NOMEM (-5)
+#define CRAG_E_INEXACT (-6)   /* crag_search_device_noalloc only: a query needs the exact fallback scan */
 
 #define CRAG_MAX_TOP_K 200    /* 2*top_k candidates <= 400 */
 
@@ -139,6 +140,26 @@ int crag_search_multi(crag_index* const* hs, const float* queries, int B, int to
 int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k, double symbol_boost,
                        const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
                        double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream);
+
+/*
+ * crag_search_device for callers that cannot allocate (code under HIP graph capture elsewhere in the process,
+ * tight serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same
+ * results, bit for bit.  It calls no hipMalloc / hipFree / hipHostMalloc and creates no stream or event: every
+ * workspace buffer is carved from one 24 MiB `static __device__` array inside the library (each GPU the library
+ * runs on holds its own copy until the process ends).
+ *   limits   B <= CRAG_NOALLOC_MAX_B (64), top_k <= CRAG_MAX_TOP_K; beyond them, or if the search would need more
+ *            than the array holds, CRAG_E_LIMIT and nothing is launched.
+ *   exactness  a query that fails its exactness certificate or overflows its candidate buffer cannot be re-run
+ *            here (the exact fallback scan needs 8 bytes of workspace per row): the call returns CRAG_E_INEXACT and
+ *            the caller repeats the batch through crag_search_device.  The outputs are not valid in that case.
+ *   sharing  all calls on one GPU use that GPU's one array, which keeps the last call's contents (the call clears
+ *            the counters it needs at zero itself): two calls that overlap on one GPU race -- serialise them.
+ * Like crag_search_device it returns after the results are complete and verified (it waits for `stream`).
+ */
+#define CRAG_NOALLOC_MAX_B 64
+int crag_search_device_noalloc(crag_index* h, const void* queries_dev, int B, int top_k, double symbol_boost,
+                               const uint64_t* q_hashes_dev, const int32_t* q_hash_off_dev, int64_t* out_ids_dev,
+                               double* out_scores_dev, float* out_dist_dev, int32_t* out_counts_dev, void* stream);
 
 /*
  * The same for ONE QUERY PER COLLECTION (query b against hs[b]; a handle may repeat): the device-buffer

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the retrieval scoring path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N child ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json metric "queries/sec @ top-10, 10M x 768 bf16 corpus, 1-8 GPUs"):
-every GPU holds a 10M x 768 bf16 shard of unit-normalised synthetic rows (weak scaling: N GPUs
-= N x 10M rows; --rows-per-gpu 12500000 gives configs[3]'s 100M rows at N=8), the query batch is
-256 (configs[3]) at top-10.  One step = one batch through the whole hot path: sample scan, tau
+every GPU holds a 10M x 768 bf16 shard of unit-normalised synthetic rows (the default, weak scaling:
+N GPUs = N x 10M rows; `--scaling strong` splits configs[3]'s fixed 100M rows over the N GPUs and
+reports merged answers per second), the query batch is 256 (configs[3]) at top-10.  One step = one batch through the whole hot path: sample scan, tau
 select, filtered scan with the fused top-k filter, exact re-score + certificate, RCCL
 all-gather of the per-shard candidates (N > 1), merge + symbol/path rerank.  Inputs (corpus,
 queries, metadata columns, symbol hashes) are resident in HBM before the timed region.
@@ -48,48 +48,127 @@ def pmc_traffic(n, d, B):
     return pmc_entry(n, d, B).get("bytes")
 
 
+def kernel_sources_sha():
+    """sha256 over the scan/select kernel sources the PMC passes were taken on (profiles/pmc_traffic.json records
+    it per entry): a committed traffic figure is only reported while the kernels it measured are the ones built."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "code-rag_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".inc", ".h")):
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_checked(n, d, B):
+    """(bytes or None, provenance string): None with the reason when there is no entry or the kernels changed."""
+    e = pmc_entry(n, d, B)
+    if not e.get("bytes"):
+        return None, "no committed rocprofv3 --pmc FETCH_SIZE pass for this workload (rocprofv3 cannot wrap itself)"
+    now = kernel_sources_sha()
+    if e.get("kernel_sources_sha") != now:
+        return None, (f"stale: {e.get('source')} was taken on kernel sources {e.get('kernel_sources_sha')}, "
+                      f"the built library is {now}; re-run tools/profile_regimes.sh")
+    return e["bytes"], f"{e.get('source')} (kernel sources {now}, git {e.get('git', '?')})"
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N child processes (one rank per GPU) with the
+    torch.distributed environment and wait for them.  This parent never touches the GPU (it imports neither
+    torch nor the library), so no process that initialised HIP is ever replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad:  # a rank died: the others would wait in a collective for ever
+                rc = bad[0]
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --rows-per-gpu rows on every GPU; strong: --total-rows (configs[3]: 100M) split over the GPUs")
     ap.add_argument("--rows-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--total-rows", type=int, default=100_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the extra regimes")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (gloo, host stand-ins for the two GPU stages): no GPU work, no valid number")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import coderag_hip as ch
-    from coderag_hip.dist import ShardedSearcher
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from coderag_hip.dist import ShardedSearcher, shard_range
+
+    if args.dry_run:
+        return dry_run(args, world, rank, np, torch, dist, ShardedSearcher, shard_range)
+    import coderag_hip as ch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    n, d, B, top_k = args.rows_per_gpu, args.dim, args.batch, args.top_k
+    d, B, top_k = args.dim, args.batch, args.top_k
+    strong = args.scaling == "strong"
+    if strong:
+        lo, hi = shard_range(args.total_rows, rank, world)
+        n, id_base, total_rows = hi - lo, lo, args.total_rows
+    else:
+        n, id_base, total_rows = args.rows_per_gpu, rank * args.rows_per_gpu, world * args.rows_per_gpu
 
     # ---- synthetic shard, generated on the device in chunks (SURVEY.md section 8d) -----------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     rows = torch.empty((n, d), dtype=torch.bfloat16, device=dev)
     step_rows = 1_000_000
-    for lo in range(0, n, step_rows):
-        m = min(step_rows, n - lo)
+    for lo_ in range(0, n, step_rows):
+        m = min(step_rows, n - lo_)
         x = torch.randn((m, d), generator=g, device=dev, dtype=torch.float32)
-        rows[lo:lo + m] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+        rows[lo_:lo_ + m] = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
     del x
     gq = torch.Generator(device=dev).manual_seed(1235)  # same queries on every rank
     q = torch.randn((max(B, 1024), d), generator=gq, device=dev, dtype=torch.float32)
@@ -100,10 +179,14 @@ def main():
     sym_hash, sym_len = ch.hash_names([f"sym{i}" for i in range(n_sym)])
     sym_hash_t = torch.from_numpy(sym_hash.view(np.int64)).to(dev)
     gz = torch.Generator(device=dev).manual_seed(99 + rank)
-    zipf = (torch.rand((n,), generator=gz, device=dev).pow(3.0) * n_sym).long().clamp_(max=n_sym - 1)
-    name_hash = sym_hash_t[zipf].contiguous()
-    u = torch.rand((n,), generator=gz, device=dev)
-    path_class = torch.where(u < 0.70, 0, torch.where(u < 0.95, 2, 1)).to(torch.uint8).contiguous()
+    name_hash = torch.empty((n,), dtype=torch.int64, device=dev)
+    path_class = torch.empty((n,), dtype=torch.uint8, device=dev)
+    for lo_ in range(0, n, 10_000_000):  # in chunks: the temporaries of 100M rows at once would be GBs
+        m = min(10_000_000, n - lo_)
+        zipf = (torch.rand((m,), generator=gz, device=dev).pow(3.0) * n_sym).long().clamp_(max=n_sym - 1)
+        name_hash[lo_:lo_ + m] = sym_hash_t[zipf]
+        u = torch.rand((m,), generator=gz, device=dev)
+        path_class[lo_:lo_ + m] = torch.where(u < 0.70, 0, torch.where(u < 0.95, 2, 1)).to(torch.uint8)
     del zipf, u
     rng = np.random.default_rng(7)
     qsyms = np.sort(sym_hash[rng.integers(0, n_sym, size=(q.shape[0], 2))], axis=1)
@@ -113,7 +196,7 @@ def main():
     col = ch.GpuCollection(d, "bf16", "l2", device=local_rank)
     col.attach_device(rows, name_hash, path_class)
     col.set_symbols(sym_hash, sym_len)
-    col.set_id_base(rank * n)
+    col.set_id_base(id_base)
     col.finalize()
     sharded = ShardedSearcher(col, rank, world) if world > 1 else None
     qb = q[:B].contiguous()
@@ -146,20 +229,26 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        fb = torch.tensor([st["fallback"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(fb)
+        st["fallback"] = int(fb.item())
     ms_per_step = dt / args.steps * 1e3
-    # unit of work = one query scored against one 10M-row shard (rows shard, queries replicate):
-    # every rank scans ITS rows for all B queries, so a step processes world * B units; the merged answer
-    # (B queries over world * n rows) is reported beside it
-    qps = world * B * args.steps / dt
-    merged_qps = B * args.steps / dt
+    merged_qps = B * args.steps / dt      # answers per second over the whole (sharded) corpus
+    # weak scaling: the unit of work is one query scored against one --rows-per-gpu shard (rows shard,
+    # queries replicate; every rank scans ITS rows for all B queries), so a step processes world x B units.
+    # strong scaling: the corpus is fixed (configs[3]), the unit is one merged answer.
+    qps = merged_qps if strong else world * merged_qps
 
-    # ---- roofline of the dominant kernel (filter-pass scan) ----------------------------------
+    # ---- roofline of the dominant kernel (filter-pass scan = last cascade level), this rank's shard -----------
     scan_ms = prof["filter_scan_ms"] / max(prof["searches"], 1)
-    scan_rows = prof["filter_scan_rows"] / max(prof["searches"], 1)   # rows minus the level-1 prefix
-    alg_bytes = int(scan_rows * (d * 2 + 4))  # rows once + |x|^2 column, per launch
+    scan_rows = prof["filter_scan_rows"] / max(prof["searches"], 1)   # rows behind the earlier levels
+    row_bytes = d * 2 + 4                   # the row once + its |x|^2
+    alg_bytes = int(scan_rows * row_bytes)
     flops = 2.0 * B * scan_rows * d
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
+    traffic, traffic_src = pmc_traffic_checked(n, d, B) if top_k == 10 else (None, "committed passes are top-10 runs")
+    step_s = ms_per_step * 1e-3
     roofline = {
         "kernel": ("k_scan_qreg2" if B >= 2 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
         "bound": "hbm" if hbm_bound else "mfma",
@@ -167,16 +256,25 @@ def main():
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,
         "unit": "GB/s" if hbm_bound else "TFLOP/s",
         "frac": round((achieved_gbs / HBM_PEAK_GBS) if hbm_bound else (flops / (scan_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF), 4),
-        "traffic": pmc_traffic(n, d, B),
+        "traffic": traffic,
+        "traffic_source": traffic_src,
         "kernel_ms": round(scan_ms, 4),
         "algorithmic_bytes": alg_bytes,
         "rows_scanned": int(scan_rows),
         "mfma_tflops": round(flops / (scan_ms * 1e-3) / 1e12, 2) if scan_ms > 0 else 0.0,
         "mfma_frac": round(flops / (scan_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4) if scan_ms > 0 else 0.0,
+        # the WHOLE step on this rank's shard: every level, every selection, finalize, (all-gather,) merge
+        "step": {"algorithmic_bytes": int(n * row_bytes), "flops": 2.0 * B * n * d, "ms": round(ms_per_step, 4),
+                 "hbm_GBps": round(n * row_bytes / step_s / 1e9, 1), "hbm_frac": round(n * row_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                 "mfma_TFLOPs": round(2.0 * B * n * d / step_s / 1e12, 2),
+                 "mfma_frac": round(2.0 * B * n * d / step_s / 1e12 / MFMA_BF16_PEAK_TF, 4)},
     }
 
+    shard_txt = (f"{total_rows} x {d} bf16 unit-norm rows split over {world} GPU(s) ({n} on rank 0)" if strong else
+                 f"{n} x {d} bf16 unit-norm rows per GPU ({total_rows} in total)")
     line = {
-        "metric": "queries/sec @ top-10, 10M x 768 bf16 corpus",
+        "metric": ("queries/sec @ top-10, 100M x 768 bf16 corpus row-sharded over the GPUs (configs[3])" if strong else
+                   "queries/sec @ top-10, 10M x 768 bf16 corpus"),
         "value": round(qps, 2),
         "unit": "queries/s",
         "n_gpus": world,
@@ -184,27 +282,28 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": f"{n} x {d} bf16 unit-norm rows per GPU ({world * n} total), batch-{B} queries, "
-                               f"top-{top_k} (2*top_k={2 * top_k} candidates), squared-L2, symbolBoost=2.0 rerank, "
-                               "row-sharded with one RCCL all-gather of candidates" if world > 1 else
-                               f"{n} x {d} bf16 unit-norm rows, batch-{B} queries, top-{top_k} "
-                               f"(2*top_k={2 * top_k} candidates), squared-L2, symbolBoost=2.0 rerank, single MI355X",
-                   "rows_per_gpu": n, "dim": d, "batch": B, "top_k": top_k, "parallelism": f"rows/{world}"},
+        "config": {"workload": f"{shard_txt}, batch-{B} queries, top-{top_k} (2*top_k={2 * top_k} candidates), squared-L2, "
+                               "symbolBoost=2.0 rerank" + (", one RCCL all-gather of candidates per batch" if world > 1 else ", single MI355X"),
+                   "rows_per_gpu": n, "total_rows": total_rows, "dim": d, "batch": B, "top_k": top_k, "parallelism": f"rows/{world}"},
         "roofline": roofline,
         "exact_fallback_queries": st["fallback"],
-        # answers per second over the WHOLE sharded corpus (every query scored against all n_gpus shards and merged);
-        # `value` counts one query against one shard as the unit, so value = n_gpus x this
         "merged_queries_per_s": round(merged_qps, 2),
     }
-    line["config"]["unit"] = (f"one query scored against one {n}-row shard; value = n_gpus x batch x steps / time; "
-                              f"merged answers over the whole {world * n}-row corpus: {merged_qps:.2f} queries/s")
+    line["config"]["unit"] = (
+        f"one merged answer over the whole {total_rows}-row corpus; value = batch x steps / time" if strong else
+        f"one query scored against one {n}-row shard (each rank scans its own rows for all {B} queries: weak scaling); "
+        f"value = n_gpus x batch x steps / time; merged answers over the whole {total_rows}-row corpus: {merged_qps:.2f} queries/s")
 
     if rank == 0 and world == 1 and not args.no_extras:
-        line["regimes"] = extra_regimes(col, q, n, d, torch)
+        line["regimes"] = [{"regime": "configs[0]: lodash via chunker.py + embed_ingest.py into Chroma, eval/qa_min.jsonl through "
+                                      "HybridSearcher top-k=8 on CPU (reference path)",
+                            "skipped": "needs the lodash checkout, the MiniLM ONNX model, chromadb and tree-sitter; none is in "
+                                       "/root/reference, this image or the GPU box, and there is no network (BASELINE.md 3.4)"}]
+        line["regimes"] += extra_regimes(col, q, n, d, torch)
         line["cpu_baseline"] = cpu_baseline(rows, q, n, d, top_k, args.cpu_sample_rows, torch, np)
         col.close()
         del col, rows, name_hash, path_class
@@ -214,6 +313,61 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dry_run(args, world, rank, np, torch, dist, ShardedSearcher, shard_range):
+    """CPU rehearsal of `--gpus N`: the launcher, the rendezvous, ShardedSearcher and its all-gather with host
+    stand-ins for the two GPU stages (synthetic sorted candidates per shard; (distance, id) merge in numpy)."""
+    entry = np.dtype([("dist", "<f4"), ("flags", "<u4"), ("id", "<i8")])
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus
+    B, top_k, kc = args.batch, args.top_k, 2 * args.top_k
+    total = args.total_rows if args.scaling == "strong" else world * args.rows_per_gpu
+    lo, hi = shard_range(total, rank, world)
+    rng = np.random.default_rng(100 + rank)
+
+    def stage1(queries, top_k_, entries, qh, qo):
+        e = np.zeros((B, kc), entry)
+        e["dist"] = np.sort(rng.random((B, kc), dtype=np.float32), axis=1)
+        e["id"] = np.sort(rng.integers(lo, hi, size=(B, kc)), axis=1)
+        entries.copy_(torch.from_numpy(e.view(np.uint8).reshape(B, kc, 16)))
+
+    def stage2(gathered, G, b, top_k_, symbol_boost):
+        g = gathered.numpy().reshape(G, b, kc * 16).view(entry)
+        ids = np.empty((b, top_k_), np.int64)
+        for i in range(b):
+            a = np.concatenate([g[r, i] for r in range(G)])
+            ids[i] = a["id"][np.lexsort((a["id"], a["dist"]))[:top_k_]]
+        return ids
+
+    s = ShardedSearcher(None, rank, world, stage1=stage1, stage2=stage2)
+    q = torch.zeros((B, args.dim))
+    for _ in range(args.warmup):
+        s.search_device(q, top_k)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = s.search_device(q, top_k)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(ids.min() >= 0 and ids.max() < total)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the multi-rank plumbing (no GPU work: not a measurement)", "dry_run": True,
+                          "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 4), "scaling": args.scaling, "merged_ids_in_range": ok,
+                          "data": "synthetic"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 def extra_regimes(col, q, n, d, torch):

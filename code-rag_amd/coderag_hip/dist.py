@@ -41,20 +41,35 @@ def all_gather_entries(local_entries, group=None):
 
 
 class ShardedSearcher:
-    """One rank's view of a row-sharded collection."""
+    """One rank's view of a row-sharded collection.
 
-    def __init__(self, collection, rank: int, world: int, group=None):
+    `stage1(queries, top_k, entries, q_hashes, q_hash_off)` fills this shard's [B, 2*top_k, 16] entries and
+    `stage2(gathered [G, B, 2*top_k, 16], G, B, top_k, symbol_boost)` merges and reranks; they default to the
+    HIP entry points (crag_search_local_device, crag_merge_rerank_device).  The CPU tests and `bench.py --dry-run`
+    pass host stand-ins for both, so that the class the bench runs is the class the gloo tests run."""
+
+    def __init__(self, collection, rank: int, world: int, group=None, stage1=None, stage2=None):
         self.col = collection  # GpuCollection holding this rank's slice, id_base already set
         self.rank, self.world, self.group = rank, world, group
         self._entries = None
+        self._stage1, self._stage2 = stage1, stage2
+        import torch.distributed as dist
+        have = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if have != world:
+            raise ValueError(f"ShardedSearcher: world={world} but the process group has {have} ranks")
 
     def search_device(self, queries, top_k: int = 10, symbol_boost: float = 2.0, q_hashes=None, q_hash_off=None):
         import torch
-        from .collection import merge_rerank_device
         b = queries.shape[0]
         kc = 2 * top_k
         if self._entries is None or tuple(self._entries.shape) != (b, kc, ENTRY_BYTES):
             self._entries = torch.empty((b, kc, ENTRY_BYTES), dtype=torch.uint8, device=queries.device)
-        self.col.search_local_device(queries, top_k, self._entries, q_hashes, q_hash_off)
+        if self._stage1 is not None:
+            self._stage1(queries, top_k, self._entries, q_hashes, q_hash_off)
+        else:
+            self.col.search_local_device(queries, top_k, self._entries, q_hashes, q_hash_off)
         gathered = all_gather_entries(self._entries, self.group)
+        if self._stage2 is not None:
+            return self._stage2(gathered, self.world, b, top_k, symbol_boost)
+        from .collection import merge_rerank_device
         return merge_rerank_device(self.col.device, gathered, self.world, b, top_k, symbol_boost)

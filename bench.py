@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the extra regimes")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
+    ap.add_argument("--path", choices=("auto", "gemv", "mfma"), default="auto", help="force a scan kernel family (A/B runs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (gloo, host stand-ins for the two GPU stages): no GPU work, no valid number")
     args = ap.parse_args()
@@ -198,6 +199,7 @@ def main():
     col.set_symbols(sym_hash, sym_len)
     col.set_id_base(id_base)
     col.finalize()
+    col.set_path(args.path)
     sharded = ShardedSearcher(col, rank, world) if world > 1 else None
     qb = q[:B].contiguous()
 

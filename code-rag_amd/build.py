@@ -68,7 +68,7 @@ def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from):
 
 
 def check_qreg2_isa(asm_path):
-    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qreg2ILi(\d+)ELi\d+E\S*):", 8,
+    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qreg2ILi(\d+)ELi\d+ELb[01]E\S*):", 12,
                              lambda m: 128 if int(m.group(2)) == 48 else None)
 
 
@@ -77,7 +77,7 @@ def check_qf32_isa(asm_path):
 
 
 def check_qsplit_isa(asm_path):
-    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qsplitILi\d+E\S*):", 2, lambda m: None)
+    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qsplitILi\d+ELb[01]E\S*):", 3, lambda m: None)
 
 
 def build(force=False, verbose=True):

@@ -95,6 +95,21 @@ __device__ __forceinline__ float butterfly64(float (&v)[64], int lane) {
     return keep + dpp_mov<0xB1>(send);  // xor 1 (quad_perm [1,0,3,2])
 }
 
+// corpus rows are read once per pass by one wave: nontemporal loads (global_load_dwordx4 ... nt) keep them from
+// displacing what the L2 is for (queries, |x|^2, descriptors)
+#ifndef CRAG_GEMV_NT
+#define CRAG_GEMV_NT 1
+#endif
+__device__ __forceinline__ uint4 load_row_chunk(const uint4* p) {
+#if CRAG_GEMV_NT
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4_t*)p);  // global, not flat
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 template <int DT, int C, int NQ>
 __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__ groups, int n_groups,
                                                    const uint4* __restrict__ queries, int pass, int metric,
@@ -165,14 +180,14 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
 #pragma unroll
         for (int n = 0; n < U; ++n) {
             const int rel = 64 * n + lane;
-            buf[n] = base[rel < rel_max ? rel : rel_max];
+            buf[n] = load_row_chunk(base + (rel < rel_max ? rel : rel_max));
         }
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
             const uint4 x = buf[n % U];
             if (n + U < NL) {
                 const int rel = 64 * (n + U) + lane;
-                buf[n % U] = base[rel < rel_max ? rel : rel_max];
+                buf[n % U] = load_row_chunk(base + (rel < rel_max ? rel : rel_max));
             }
             const int row_lo = (64 * n) / C;
             const int row_hi = (64 * n + 63) / C;

@@ -47,7 +47,9 @@ struct QsplitDma {            // one half-tile to prefetch (all wave-uniform)
 
 #include "crag_qsplit_kloop.inc"
 
-template <int MODE>
+// NT: one query group per launch, so every tile is read by exactly one workgroup: nontemporal DMA loads (see
+// crag_scan_qreg2.hip)
+template <int MODE, bool NT>
 __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned short* __restrict__ rows,
                                                                   const float* __restrict__ xnorm, long long row_begin,
                                                                   long long row_end, const unsigned short* __restrict__ queries,
@@ -118,13 +120,13 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
                 }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + off),
                                                  (__attribute__((address_space(3))) void*)(lds + buf * QS_HALF + (wave + QS_WAVES * i + 16 * h) * QS_HROWB),
-                                                 16, 0, 0);
+                                                 16, 0, NT ? 2 : 0);
             }
         }
         const float* gx = xnorm + row0 + lane;  // xnorm is padded by >= 256 floats
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
                                          (__attribute__((address_space(3))) void*)(lds + QS_XN_BASE + (buf * QS_WAVES + wave) * QS_XN_BYTES),
-                                         4, 0, 0);
+                                         4, 0, NT ? 2 : 0);
     };
 
     const unsigned a_lane = lds_base + fr * QS_HROWB + ((fh ^ (fr & 15)) << 4);
@@ -162,10 +164,10 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
             f32x16_t acc, xs;
             float mn;
             QsplitDma d0 = half_desc(t1, 1, b3), d1 = half_desc(t2, 0, b4);
-            if (dma0 && dma1) QsplitTile<true, true>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
-            else if (dma0) QsplitTile<true, false>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
-            else if (dma1) QsplitTile<false, true>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
-            else QsplitTile<false, false>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            if (dma0 && dma1) QsplitTile<true, true, NT>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            else if (dma0) QsplitTile<true, false, NT>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            else if (dma1) QsplitTile<false, true, NT>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            else QsplitTile<false, false, false>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
             if (ex4 && !dma1) issue(t2, 0, b4);  // ragged: after the mid-tile rendezvous freed buffer h
             drained = !(dma0 && dma1);
             const unsigned mb = (unsigned)t * QS_TM + 4 * fh, re = (unsigned)row_end;  // rows per collection < 2^32
@@ -225,19 +227,20 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
     }
 }
 
-int launch_mode(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
+template <int MODE, bool NT>
+int launch_one(const MfmaArgs& a, int grid, int nqg, hipStream_t s) {
     const size_t lds = (size_t)QS_NBUF * QS_HALF + (size_t)QS_NBUF * QS_WAVES * QS_XN_BYTES;
-    static std::atomic<uint64_t> lds_ok[2];
-    crag_allow_dynamic_lds(mode == 0 ? (const void*)k_scan_qsplit<0> : (const void*)k_scan_qsplit<1>, lds, lds_ok[mode]);
-    if (mode == 0)
-        hipLaunchKernelGGL((k_scan_qsplit<0>), dim3(grid), dim3(64 * QS_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
-                           a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau,
-                           a.sample, a.sample_stride, a.cand, a.cnt);
-    else
-        hipLaunchKernelGGL((k_scan_qsplit<1>), dim3(grid), dim3(64 * QS_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
-                           a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau,
-                           a.sample, a.sample_stride, a.cand, a.cnt);
+    static std::atomic<uint64_t> lds_ok;
+    crag_allow_dynamic_lds((const void*)k_scan_qsplit<MODE, NT>, lds, lds_ok);
+    hipLaunchKernelGGL((k_scan_qsplit<MODE, NT>), dim3(grid), dim3(64 * QS_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
+                       a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau,
+                       a.sample, a.sample_stride, a.cand, a.cnt);
     return (int)hipGetLastError();
+}
+
+int launch_mode(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
+    if (mode == 0) return launch_one<0, false>(a, grid, nqg, s);
+    return nqg == 1 ? launch_one<1, true>(a, grid, nqg, s) : launch_one<1, false>(a, grid, nqg, s);
 }
 
 }  // namespace

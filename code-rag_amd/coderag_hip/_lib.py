@@ -22,7 +22,7 @@ SYMBOLS = [
     "crag_version", "crag_last_error", "crag_device_count",
     "crag_index_create", "crag_index_destroy", "crag_index_size", "crag_index_dim_pad",
     "crag_index_set_id_base", "crag_index_add", "crag_index_add_device", "crag_index_attach_device",
-    "crag_index_set_symbols", "crag_index_finalize",
+    "crag_index_set_symbols", "crag_index_finalize", "crag_index_get_rows",
     "crag_hash_name", "crag_hash_names", "crag_symbol_hashes",
     "crag_search", "crag_search_multi", "crag_search_device", "crag_search_multi_device",
     "crag_search_device_noalloc",
@@ -83,6 +83,7 @@ def load() -> C.CDLL:
     lib.crag_index_attach_device.argtypes = [vp, vp, i64, vp, vp]
     lib.crag_index_set_symbols.argtypes = [vp, vp, vp, i64]
     lib.crag_index_finalize.argtypes = [vp]
+    lib.crag_index_get_rows.argtypes = [vp, i64, i64, vp]
     lib.crag_hash_name.argtypes = [C.c_char_p, i64]
     lib.crag_hash_name.restype = C.c_uint64
     lib.crag_hash_names.argtypes = [C.c_char_p, vp, i64, vp]

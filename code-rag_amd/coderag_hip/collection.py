@@ -170,6 +170,13 @@ class GpuCollection:
         self._keep = [rows, name_hash, path_class]
         self._finalized = False
 
+    def rows_host(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """Rows [first, first + n) copied back from the device: float32 [n, dim], or uint16 bf16 bit patterns."""
+        n = len(self) - first if n is None else int(n)
+        out = np.empty((n, self.dim), np.float32 if self.dtype == "f32" else np.uint16)
+        check(self._lib.crag_index_get_rows(self._h, int(first), n, out.ctypes.data), "crag_index_get_rows")
+        return out
+
     def set_symbols(self, hashes: np.ndarray, lens: np.ndarray):
         hashes = np.ascontiguousarray(hashes, np.uint64)
         lens = np.ascontiguousarray(lens, np.uint16)

@@ -14,19 +14,26 @@ the resolved collection name, as in api/main.py:175-176.
 import json
 from typing import List, Optional
 
-from fastapi import FastAPI, Header
+from fastapi import FastAPI, Header, Query
 from pydantic import BaseModel, Field
 
 from .api import get_collection_name, search_route
 
 
-class SearchRequest(BaseModel):
-    query: str = Field(..., min_length=1)
-    top_k: int = 10
-    symbol_boost: float = 2.0
-    path_prefix: Optional[str] = None
-    kind: Optional[str] = None
-    min_score: Optional[float] = None
+def make_search_request(defaults: dict):
+    """The reference's request model (api/main.py:143-149) with its two defaults taken from configs/retrieval.yaml
+    `searchDefaults` (10 and 2.0 there as well).  top_k is validated here: the kernels serve 1..200
+    (CRAG_MAX_TOP_K); the reference has no upper limit, so a larger value is a 422 here instead of a 500."""
+
+    class SearchRequest(BaseModel):
+        query: str = Field(..., min_length=1)
+        top_k: int = Field(int(defaults.get("top_k", 10)), ge=1, le=200)
+        symbol_boost: float = float(defaults.get("symbol_boost", 2.0))
+        path_prefix: Optional[str] = None
+        kind: Optional[str] = None
+        min_score: Optional[float] = None
+
+    return SearchRequest
 
 
 class SearchResult(BaseModel):
@@ -48,6 +55,8 @@ class SearchResponse(BaseModel):
 
 def build_app(searcher, cache=None) -> FastAPI:
     app = FastAPI(title="code-rag retrieval (MI355X scoring path)")
+    cfg = getattr(searcher, "config", None) or {}
+    SearchRequest = make_search_request(cfg.get("searchDefaults", {}))
 
     @app.post("/search", response_model=SearchResponse)
     def search(req: SearchRequest, x_workspace_id: Optional[str] = Header(None)):
@@ -67,7 +76,7 @@ def build_app(searcher, cache=None) -> FastAPI:
         return resp
 
     @app.get("/search/{symbol}")
-    def search_symbol(symbol: str, top_k: int = 10, x_workspace_id: Optional[str] = Header(None)):
+    def search_symbol(symbol: str, top_k: int = Query(10, ge=1, le=200), x_workspace_id: Optional[str] = Header(None)):
         rows = searcher.search_by_symbol(symbol, top_k=top_k, collection_name=get_collection_name(x_workspace_id))
         return {"symbol": symbol, "total": len(rows), "results": rows}
 

@@ -12,12 +12,14 @@ and is out of scope; see embed.py for the offline stand-in).
 from __future__ import annotations
 
 import threading
-from typing import Any, Callable, Dict, List, Optional, Sequence
+from concurrent.futures import ThreadPoolExecutor
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .collection import GpuCollection, lowered_name_bytes
+from .collection import GpuCollection, lowered_name_bytes, search_multi
 from ._lib import CragError
+from .config import load_retrieval_config
 from .embed import HashingEmbedder
 from . import store
 
@@ -34,12 +36,15 @@ class ChunkCollection:
         self.documents: List[Optional[str]] = []
         self._by_name: Dict[Any, List[int]] = {}
         self._bucket: Dict[int, set] = {}
-        self._rows_parts: List[np.ndarray] = []  # host copy of the embeddings, for store.save_collection
 
-    def _host_rows(self) -> np.ndarray:
-        if not self._rows_parts:
-            return np.zeros((0, self.gpu.dim), np.float32)
-        return np.concatenate(self._rows_parts, 0)
+    @property
+    def device(self) -> int:
+        return self.gpu.device
+
+    def _host_rows(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """The embeddings as the GPU holds them (float32, or uint16 bf16 bit patterns), read back on demand:
+        persistence needs them once, so no second copy lives in host memory."""
+        return self.gpu.rows_host(first, n)
 
     def add(self, ids: Sequence[str], embeddings: np.ndarray, metadatas: Optional[Sequence[Optional[dict]]] = None,
             documents: Optional[Sequence[Optional[str]]] = None):
@@ -49,7 +54,6 @@ class ChunkCollection:
         names = [str((m or {}).get("name", "")) for m in metadatas]          # hybrid_search.py:98
         paths = [str((m or {}).get("path", "")) for m in metadatas]          # hybrid_search.py:99
         self.gpu.add(np.asarray(embeddings), names=names, paths=paths)
-        self._rows_parts.append(np.array(embeddings, copy=True))
         base = len(self.ids)
         self.ids.extend(ids)
         self.metadatas.extend(metadatas)
@@ -75,24 +79,61 @@ class ChunkCollection:
                     raise CragError(f"symbol hash collision on {nm!r}; refusing to return a wrong boost")
 
 
+def group_requests(keys: Sequence[Optional[Tuple]]) -> List[List[int]]:
+    """Requests of one search_many call -> grouped launches.  keys[i] is None for a request that needs no launch
+    (missing or empty collection), else (device, dim, dtype, metric, collection identity).  One group per
+    (device, dim, dtype, metric) -- a grouped launch needs one geometry on one GPU -- and inside a group the
+    requests on one collection are adjacent (they share a pass over its rows), otherwise in request order."""
+    groups: Dict[Tuple, List[int]] = {}
+    for i, k in enumerate(keys):
+        if k is not None:
+            groups.setdefault(tuple(k[:4]), []).append(i)
+    out = []
+    for idx in groups.values():
+        first_seen: Dict[Any, int] = {}
+        for i in idx:
+            first_seen.setdefault(keys[i][4], i)
+        out.append(sorted(idx, key=lambda i: (first_seen[keys[i][4]], i)))
+    return out
+
+
 class HybridSearcher:
     def __init__(self, db_path: str = "data/chroma_db", embed_fn: Optional[Callable[[List[str]], np.ndarray]] = None,
-                 device: int = 0, dtype: str = "f32"):
+                 device: int = 0, dtype: Optional[str] = None, devices: Optional[Sequence[int]] = None,
+                 config: Optional[Dict[str, Any]] = None):
+        """`devices`: the GPUs this searcher may place collections on.  Whole collections are placed round-robin in
+        the order they are created or first loaded (64 workspaces over 8 GPUs = 8 each, so a
+        query never needs a collective); `device` is the single-GPU shorthand.  `config`: the retrieval knobs
+        (coderag_hip.config.load_retrieval_config(); read from configs/retrieval.yaml when None)."""
         self.db_path = db_path
         self.ef = embed_fn if embed_fn is not None else HashingEmbedder()
-        self.device = device
-        self.dtype = dtype
+        self.devices = [int(d) for d in devices] if devices else [int(device)]
+        self.device = self.devices[0]
+        self.config = config if config is not None else load_retrieval_config()
+        self.dtype = dtype or self.config["dtype"]
+        self.metric = self.config["metric"]
         self._cols: Dict[str, ChunkCollection] = {}
+        self._placed = 0
         self._lock = threading.Lock()  # the reference mutates _cols from threadpool threads without one
+        self._loading: Dict[str, threading.Lock] = {}
+        self._pool: Optional[ThreadPoolExecutor] = None
+
+    def _next_device(self) -> int:
+        """round-robin placement slot (call with self._lock held)"""
+        d = self.devices[self._placed % len(self.devices)]
+        self._placed += 1
+        return d
 
     # ---- collections -----------------------------------------------------------------
-    def create_collection(self, name: str, dim: int, dtype: Optional[str] = None, metric: str = "l2",
-                          fresh: bool = True) -> ChunkCollection:
+    def create_collection(self, name: str, dim: int, dtype: Optional[str] = None, metric: Optional[str] = None,
+                          fresh: bool = True, device: Optional[int] = None) -> ChunkCollection:
         """embed_ingest.py:38-54 (`ensure_collection`): default space l2."""
         with self._lock:
             if not fresh and name in self._cols:
                 return self._cols[name]
-            col = ChunkCollection(name, dim, dtype or self.dtype, metric, self.device)
+            old = self._cols.get(name)
+            dev = device if device is not None else (old.device if old is not None else self._next_device())
+            col = ChunkCollection(name, dim, dtype or self.dtype, metric or self.metric, dev)
             self._cols[name] = col
             return col
 
@@ -100,17 +141,31 @@ class HybridSearcher:
         with self._lock:
             if name in self._cols:
                 return self._cols[name]
-        try:
-            col = store.load_collection(self.db_path, name, device=self.device)     # :33
-        except Exception:
-            return None                                                              # :36-39
-        with self._lock:
-            self._cols[name] = col
-        return col
+            load_lock = self._loading.setdefault(name, threading.Lock())
+        with load_lock:  # two threads asking for one unloaded collection: the second waits and finds it loaded
+            with self._lock:
+                if name in self._cols:
+                    return self._cols[name]
+                dev = self._next_device()
+            try:
+                col = store.load_collection(self.db_path, name, device=dev)         # :33
+            except Exception:
+                with self._lock:
+                    self._placed -= 1
+                return None                                                          # :36-39
+            with self._lock:
+                self._cols[name] = col
+            return col
 
     # ---- search ------------------------------------------------------------------------
+    def _knobs(self, top_k, symbol_boost) -> Tuple[int, float]:
+        """None -> the configured knob (configs/retrieval.yaml: topK, symbolBoost)"""
+        return (int(self.config["topK"]) if top_k is None else int(top_k),
+                float(self.config["symbolBoost"]) if symbol_boost is None else float(symbol_boost))
+
     def search(self, query: str, top_k: int = 10, symbol_boost: float = 2.0, include_documents: bool = False,
                collection_name: str = "code_chunks") -> List[Dict[str, Any]]:
+        top_k, symbol_boost = self._knobs(top_k, symbol_boost)
         col = self._get_col(collection_name)
         if not col:
             return []                                                                # :54-56
@@ -122,6 +177,7 @@ class HybridSearcher:
     def search_batch(self, queries: Sequence[str], top_k: int = 10, symbol_boost: float = 2.0,
                      include_documents: bool = False, collection_name: str = "code_chunks",
                      embeddings: Optional[np.ndarray] = None) -> List[List[Dict[str, Any]]]:
+        top_k, symbol_boost = self._knobs(top_k, symbol_boost)
         col = self._get_col(collection_name)
         if not col or col.count() == 0:
             return [[] for _ in queries]
@@ -129,28 +185,69 @@ class HybridSearcher:
         return self._search_vectors(col, vec.reshape(len(queries), -1), list(queries), top_k, symbol_boost,
                                     include_documents)
 
+    @staticmethod
+    def _result_dicts(col: ChunkCollection, ids_b, scores_b, count: int, include_documents: bool) -> List[Dict[str, Any]]:
+        res = []
+        for j in range(int(count)):
+            pos = int(ids_b[j])
+            doc_text = col.documents[pos] if include_documents else None            # :73
+            res.append({
+                "id": col.ids[pos],
+                "score": float(scores_b[j]),
+                "metadata": col.metadatas[pos] or {},                               # :78
+                "text_full": doc_text,
+                "text_preview": (doc_text or "")[:80].replace("\n", " "),           # :89
+            })
+        return res
+
     def _search_vectors(self, col: ChunkCollection, vec: np.ndarray, queries: List[str], top_k: int,
                         symbol_boost: float, include_documents: bool) -> List[List[Dict[str, Any]]]:
         for q in queries:
             col.check_symbol_hashes(q)
         ids, scores, _dists, counts = col.gpu.search(vec, top_k=top_k, symbol_boost=symbol_boost, query_texts=queries)
-        out: List[List[Dict[str, Any]]] = []
-        for b in range(len(queries)):
-            res = []
-            for j in range(int(counts[b])):
-                pos = int(ids[b, j])
-                doc_text = col.documents[pos] if include_documents else None        # :73
-                res.append({
-                    "id": col.ids[pos],
-                    "score": float(scores[b, j]),
-                    "metadata": col.metadatas[pos] or {},                           # :78
-                    "text_full": doc_text,
-                    "text_preview": (doc_text or "")[:80].replace("\n", " "),       # :89
-                })
-            out.append(res)
+        return [self._result_dicts(col, ids[b], scores[b], counts[b], include_documents) for b in range(len(queries))]
+
+    def search_many(self, queries: Sequence[str], collection_names: Sequence[str], top_k: int = 10,
+                    symbol_boost: float = 2.0, include_documents: bool = False,
+                    embeddings: Optional[np.ndarray] = None) -> List[List[Dict[str, Any]]]:
+        """One query per collection, many workspaces at once (api/main.py:77-82: one collection per workspace; a
+        threadpool of /search handlers in the reference).  Requests are grouped by the GPU their collection lives
+        on; each group is ONE grouped launch (crag_search_multi) and the groups run concurrently, one host thread
+        per device -- no cross-GPU traffic, because collections are placed whole.  Missing or empty collections
+        give [] like search()."""
+        top_k, symbol_boost = self._knobs(top_k, symbol_boost)
+        n = len(queries)
+        if len(collection_names) != n:
+            raise ValueError("one collection name per query")
+        cols = [self._get_col(c) for c in collection_names]
+        out: List[List[Dict[str, Any]]] = [[] for _ in range(n)]
+        live = [i for i in range(n) if cols[i] is not None and cols[i].count() > 0]
+        if not live:
+            return out
+        vec = np.asarray(embeddings if embeddings is not None else self.ef(list(queries)), np.float32).reshape(n, -1)
+        for i in live:
+            cols[i].check_symbol_hashes(queries[i])
+        alive = set(live)
+        groups = group_requests([(cols[i].gpu.device, cols[i].gpu.dim, cols[i].gpu.dtype, cols[i].gpu.metric, id(cols[i]))
+                                 if i in alive else None for i in range(n)])
+
+        def run(idx: List[int]):
+            ids, scores, _d, counts = search_multi([cols[i].gpu for i in idx], vec[idx], top_k, symbol_boost,
+                                                   [queries[i] for i in idx])
+            for b, i in enumerate(idx):
+                out[i] = self._result_dicts(cols[i], ids[b], scores[b], counts[b], include_documents)
+
+        if len(groups) == 1:
+            run(groups[0])
+        else:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=max(2, len(self.devices)), thread_name_prefix="coderag-dev")
+            for f in [self._pool.submit(run, g) for g in groups]:
+                f.result()
         return out
 
     def search_by_symbol(self, symbol: str, top_k: int = 10, collection_name: str = "code_chunks"):
+        top_k = self._knobs(top_k, None)[0]
         col = self._get_col(collection_name)
         if not col:
             return []                                                                # :130-131

@@ -20,7 +20,11 @@ from typing import Any, Callable, Dict, Iterable, List, Optional
 import numpy as np
 
 
+ROWS_PER_SLICE = 262144  # rows moved between disk, host and device at a time
+
+
 def sanitize_metadata(meta: Dict[str, Any]) -> Dict[str, Any]:
+    """Taken from the reference (indexer/embed_ingest.py:26-35) as it stands: its output is the metadata contract."""
     out = {}
     for k, v in meta.items():
         if v is None:
@@ -40,6 +44,7 @@ def chunk_id(meta: Dict[str, Any]) -> str:
 
 
 def iter_jsonl(path: str):
+    """Taken from the reference (indexer/embed_ingest.py:18-24) as it stands."""
     with open(path, "r", encoding="utf-8") as f:
         for line in f:
             line = line.strip()
@@ -50,8 +55,15 @@ def iter_jsonl(path: str):
 def save_collection(db_path: str, col) -> str:
     d = os.path.join(db_path, col.name)
     os.makedirs(d, exist_ok=True)
-    rows = col._host_rows()
-    np.save(os.path.join(d, "rows.npy"), rows)
+    # rows come back from the device in slices and go straight into the .npy file: no whole-matrix host copy
+    n, dim = col.count(), col.gpu.dim
+    out = np.lib.format.open_memmap(os.path.join(d, "rows.npy"), mode="w+",
+                                    dtype=np.float32 if col.gpu.dtype == "f32" else np.uint16, shape=(n, dim))
+    for lo in range(0, n, ROWS_PER_SLICE):
+        m = min(ROWS_PER_SLICE, n - lo)
+        out[lo:lo + m] = col._host_rows(lo, m)
+    out.flush()
+    del out
     with open(os.path.join(d, "chunks.jsonl"), "w", encoding="utf-8") as f:
         for cid, m, doc in zip(col.ids, col.metadatas, col.documents):
             f.write(json.dumps({"id": cid, "meta": m, "text": doc}, ensure_ascii=False) + "\n")
@@ -65,17 +77,29 @@ def load_collection(db_path: str, name: str, device: int = 0):
     d = os.path.join(db_path, name)
     with open(os.path.join(d, "meta.json")) as f:
         meta = json.load(f)
-    rows = np.load(os.path.join(d, "rows.npy"), allow_pickle=False)
+    rows = np.load(os.path.join(d, "rows.npy"), mmap_mode="r", allow_pickle=False)  # paged in slice by slice
     col = ChunkCollection(name, meta["dim"], meta["dtype"], meta.get("metric", "l2"), device)
     ids, metas, docs = [], [], []
+    done = 0
+
+    def flush():
+        nonlocal done
+        if ids:
+            col.add(list(ids), np.ascontiguousarray(rows[done:done + len(ids)]), list(metas), list(docs))
+            done += len(ids)
+            ids.clear()
+            metas.clear()
+            docs.clear()
+
     for obj in iter_jsonl(os.path.join(d, "chunks.jsonl")):
         ids.append(obj["id"])
         metas.append(obj.get("meta"))
         docs.append(obj.get("text"))
-    if len(ids) != rows.shape[0]:
+        if len(ids) >= ROWS_PER_SLICE:
+            flush()
+    flush()
+    if done != rows.shape[0]:
         raise ValueError("rows.npy and chunks.jsonl disagree")
-    if ids:
-        col.add(ids, rows, metas, docs)
     col.gpu.finalize()
     return col
 

@@ -200,6 +200,7 @@ struct WsGuard {
 };
 
 const int kChunkSizes[] = {32, 48, 64, 96, 128, 192, 256};
+constexpr int64_t CRAG_MAX_ROWS = (1ll << 32) - 64;  // candidate keys store the row number in 32 bits
 
 inline uint64_t fnv1a(const unsigned char* p, int64_t n) {
     uint64_t h = 1469598103934665603ull;
@@ -289,6 +290,7 @@ int add_common(crag_index* h, const void* rows, int64_t n, const uint64_t* name_
                hipMemcpyKind kind) {
     if (!h || n < 0 || (n > 0 && !rows)) return fail(CRAG_E_INVALID, "crag_index_add: bad arguments");
     if (n == 0) return 0;
+    if (h->n_rows + n > CRAG_MAX_ROWS) return fail(CRAG_E_LIMIT, "crag_index_add: a collection holds at most 2^32 - 64 rows (candidate keys carry the row in 32 bits)");
     HIPCHK(hipSetDevice(h->device));
     int rc = grow(h, h->n_rows + n, name_hash != nullptr, path_class != nullptr);
     if (rc) return rc;
@@ -410,9 +412,27 @@ int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, i
     return 0;
 }
 
+int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
+                                const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
+                                hipStream_t st, const MergeOut* mo);
+
+// An error return after the first launch must not hand the workspace back to the pool (or the caller's output
+// buffers back to the caller) while kernels may still be reading and writing them: wait for the stream first.
 int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                          const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
                          hipStream_t st, const MergeOut* mo) {
+    const int rc = search_entries_chunk_launch(hs, same_handle, q_dev, B, top_k, qh_dev, qhoff_dev, entries_dev, ws, st, mo);
+    if (rc) {
+        const std::string keep = g_err;  // the wait must not replace the message of what went wrong
+        (void)hipStreamSynchronize(st);
+        g_err = keep;
+    }
+    return rc;
+}
+
+int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
+                                const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
+                                hipStream_t st, const MergeOut* mo) {
     crag_index* h0 = hs[0];
     Plan P;
     P.B = B;
@@ -1148,6 +1168,7 @@ int crag_index_attach_device(crag_index* h, const void* rows_dev, int64_t n, con
                              const uint8_t* path_class_dev) {
     if (!h || !rows_dev || n < 0) return fail(CRAG_E_INVALID, "crag_index_attach_device: bad arguments");
     if (h->n_rows != 0) return fail(CRAG_E_STATE, "crag_index_attach_device: collection already holds rows");
+    if (n > CRAG_MAX_ROWS) return fail(CRAG_E_LIMIT, "crag_index_attach_device: a collection holds at most 2^32 - 64 rows");
     if (h->dim != h->dim_pad) return fail(CRAG_E_INVALID, "crag_index_attach_device: dim must equal crag_index_dim_pad");
     if (((uintptr_t)rows_dev) & 15) return fail(CRAG_E_INVALID, "crag_index_attach_device: rows must be 16-byte aligned");
     h->rows = const_cast<void*>(rows_dev);
@@ -1159,6 +1180,17 @@ int crag_index_attach_device(crag_index* h, const void* rows_dev, int64_t n, con
     h->n_rows = n;
     h->cap_rows = n;
     h->finalized = false;
+    return 0;
+}
+
+int crag_index_get_rows(const crag_index* h, int64_t first, int64_t n, void* out_rows) {
+    if (!h || first < 0 || n < 0 || first + n > h->n_rows || (n > 0 && !out_rows))
+        return fail(CRAG_E_INVALID, "crag_index_get_rows: bad arguments");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t src_pitch = (size_t)h->dim_pad * h->esz, dst_pitch = (size_t)h->dim * h->esz;
+    HIPCHK(hipMemcpy2D(out_rows, dst_pitch, (const char*)h->rows + (size_t)first * src_pitch, src_pitch, dst_pitch, (size_t)n,
+                       hipMemcpyDeviceToHost));
     return 0;
 }
 

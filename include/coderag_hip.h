@@ -11,6 +11,8 @@
  *   Collection.add(ids, documents, metadatas)              crag_index_add / _add_device /
  *     (indexer/embed_ingest.py:93)                         _attach_device, crag_index_finalize
  *   Collection.count() (indexer/embed_ingest.py:107)       crag_index_size
+ *   Collection.get(include=["embeddings"]) (Chroma API;    crag_index_get_rows
+ *     the persistence behind data/chroma_db)
  *   Collection.query(query_texts=[q], n_results=2*top_k)   crag_search (host buffers),
  *     + base score + path/symbol boost + filter + sort     crag_search_device (device buffers)
  *     + [:top_k]  (retriever/hybrid_search.py:60-125)
@@ -92,6 +94,11 @@ int crag_index_attach_device(crag_index* h, const void* rows_dev, int64_t n, con
  * per-row hashes were produced on the device.  crag_index_add with name_len builds it itself.
  */
 int crag_index_set_symbols(crag_index* h, const uint64_t* hashes, const uint16_t* lens, int64_t n);
+/*
+ * Copy rows [first, first + n) back to HOST memory as [n][dim] in the index dtype (bf16 = uint16 bit patterns):
+ * what persistence writes to disk, so that no second copy of the embeddings has to live in host memory.
+ */
+int crag_index_get_rows(const crag_index* h, int64_t first, int64_t n, void* out_rows);
 /* Row norms + bounds; required after the last add and before the first search. */
 int crag_index_finalize(crag_index* h);
 

@@ -633,6 +633,86 @@ def test_hybrid_searcher_end_to_end(tmp_path, dtype):
         assert resp.json() == {"symbol": "Parser", "total": len(got), "results": got}
 
 
+def test_search_many_places_collections_and_groups_launches(tmp_path):
+    """64-workspace serving in miniature: a searcher with two placement slots (both GPU 0 here: a one-GPU box stands
+    in for two devices), collections placed round-robin, one search_many call = one grouped launch per slot run from
+    two host threads, every answer equal to search() on its own collection; config knobs when top_k is None."""
+    rng = np.random.default_rng(62)
+    emb = ch.HashingEmbedder()
+    hs = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=emb, devices=[0, 0],
+                           config={"topK": 4, "symbolBoost": 3.0, "searchDefaults": {"top_k": 10, "symbol_boost": 2.0},
+                                   "metric": "l2", "dtype": "f32"})
+    names = []
+    for w, n in enumerate([700, 50, 2300, 1, 900]):
+        ids, metas, docs = _chunks(n, rng)
+        col = hs.create_collection(f"code_chunks__w{w}", 384)
+        col.add([f"{w}-{i}" for i in ids], emb(docs), metas, docs)
+        col.gpu.finalize()
+        names.append(col.name)
+    hs.create_collection("code_chunks__empty", 384).gpu.finalize()
+    assert hs._placed == 6
+    queries = ["Find the implementation of lodash chunk", "What does asciiToArray do?", "stringSize hasUnicode Parser", "zzz",
+               "debounce map a", "baseFlatten", "chunk again", "isArrayLike castPath"]
+    cn = [names[0], names[2], names[1], "code_chunks__nope", names[4], names[3], names[0], "code_chunks__empty"]
+    for kw in (dict(top_k=8, symbol_boost=2.0), dict(top_k=3, symbol_boost=0.3, include_documents=True), dict(top_k=None, symbol_boost=None)):
+        got = hs.search_many(queries, cn, **kw)
+        want = [hs.search(q, collection_name=c, **kw) for q, c in zip(queries, cn)]
+        assert got == want
+        assert got[3] == [] and got[7] == []
+    assert len(hs.search_many(queries[:1], cn[:1], top_k=None)[0]) == 4          # topK from the config
+    # persistence without a host copy of the embeddings: rows are read back from the device
+    from coderag_hip import store
+    col = hs._cols[names[2]]
+    store.save_collection(str(tmp_path), col)
+    assert not hasattr(col, "_rows_parts")
+    saved = np.load(os.path.join(str(tmp_path), names[2], "rows.npy"))
+    assert saved.shape == (2300, 384) and np.array_equal(saved, col.gpu.rows_host())
+    hs2 = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=emb, devices=[0, 0])
+    assert hs2.search(queries[1], 8, collection_name=names[2]) == hs.search(queries[1], 8, collection_name=names[2])
+    # bf16 collections persist their bit patterns
+    hb = ch.HybridSearcher(db_path=str(tmp_path / "b"), embed_fn=emb, dtype="bf16")
+    ids, metas, docs = _chunks(300, rng)
+    cb = hb.create_collection("code_chunks__b", 384)
+    cb.add(ids, emb(docs), metas, docs)
+    cb.gpu.finalize()
+    store.save_collection(hb.db_path, cb)
+    assert np.load(os.path.join(hb.db_path, "code_chunks__b", "rows.npy")).dtype == np.uint16
+    hb2 = ch.HybridSearcher(db_path=hb.db_path, embed_fn=emb, dtype="bf16")
+    assert hb2.search(queries[0], 8, collection_name="code_chunks__b") == hb.search(queries[0], 8, collection_name="code_chunks__b")
+    # the HTTP route validates top_k (CRAG_MAX_TOP_K) instead of failing inside the library
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from fastapi.testclient import TestClient
+        client = TestClient(ch.create_app(hs))
+        assert client.post("/search", json={"query": "x", "top_k": 201}, headers={"X-Workspace-Id": "w0"}).status_code == 422
+        assert client.post("/search", json={"query": "x", "top_k": 0}, headers={"X-Workspace-Id": "w0"}).status_code == 422
+        assert client.post("/search", json={"query": "chunk", "top_k": 200}, headers={"X-Workspace-Id": "w0"}).status_code == 200
+
+
+def test_concurrent_first_access_loads_a_collection_once(tmp_path):
+    from coderag_hip import store
+    rng = np.random.default_rng(63)
+    emb = ch.HashingEmbedder()
+    hs = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=emb)
+    ids, metas, docs = _chunks(400, rng)
+    col = hs.create_collection("code_chunks__c", 384)
+    col.add(ids, emb(docs), metas, docs)
+    col.gpu.finalize()
+    store.save_collection(hs.db_path, col)
+    hs2 = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=emb)
+    seen, res = [], []
+
+    def work():
+        res.append(hs2.search("chunk", 5, collection_name="code_chunks__c"))
+        seen.append(id(hs2._cols["code_chunks__c"]))
+
+    ts = [threading.Thread(target=work) for _ in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(set(seen)) == 1 and hs2._placed == 1 and all(r == res[0] and len(r) == 5 for r in res)
+
+
 def test_ingest_chunks_from_jsonl(tmp_path):
     """The step before the path (indexer/embed_ingest.py:57-132): the chunker's JSONL -> collection in batches,
     metadata sanitised, persisted, found again by a fresh searcher; records without an id get the chunker's."""

@@ -186,3 +186,75 @@ def test_search_routes_over_http_keep_the_reference_shape():
         r = client.get("/search/Parser", params={"top_k": 4}, headers={"X-Workspace-Id": "default"})
         assert r.json() == {"symbol": "Parser", "total": 1, "results": [{"id": "a", "score": 1.0}]}
         assert fs.calls[-1] == ("sym", "Parser", 4, "code_chunks")
+
+
+# ---- configs/retrieval.yaml (north_star: "the configs/retrieval.yaml knobs (topK, symbolBoost) ... stay unchanged") ----
+def test_retrieval_config_file_is_read(tmp_path):
+    cfg = ch.load_retrieval_config()                       # this repository's configs/retrieval.yaml
+    assert cfg["topK"] == 8 and cfg["symbolBoost"] == 2.0  # clients/vscode/package.json:75-84
+    assert cfg["searchDefaults"] == {"top_k": 10, "symbol_boost": 2.0}   # api/main.py:145-146
+    p = tmp_path / "retrieval.yaml"
+    p.write_text("topK: 5\nsymbolBoost: 3.5\nsearchDefaults:\n  top_k: 7\ndtype: bf16\n")
+    cfg = ch.load_retrieval_config(str(p))
+    assert (cfg["topK"], cfg["symbolBoost"], cfg["dtype"], cfg["metric"]) == (5, 3.5, "bf16", "l2")
+    assert cfg["searchDefaults"] == {"top_k": 7, "symbol_boost": 2.0}
+    empty = tmp_path / "empty.yaml"                        # the reference's own file is 0 bytes: defaults
+    empty.write_text("")
+    assert ch.load_retrieval_config(str(empty))["topK"] == 8
+    p.write_text("topK: 500\n")
+    with pytest.raises(ValueError):
+        ch.load_retrieval_config(str(p))
+
+
+def test_searcher_takes_its_knobs_from_the_config():
+    hs = ch.HybridSearcher(db_path="unused", config={"topK": 5, "symbolBoost": 3.5, "searchDefaults": {"top_k": 7, "symbol_boost": 2.0},
+                                                     "metric": "ip", "dtype": "bf16"})
+    assert hs._knobs(None, None) == (5, 3.5)               # None -> the configured knob
+    assert hs._knobs(10, 2.0) == (10, 2.0)                 # an explicit value wins (the signature defaults are explicit)
+    assert (hs.dtype, hs.metric) == ("bf16", "ip")
+    import inspect
+    sig = inspect.signature(hs.search)                      # the reference's signature stays (hybrid_search.py:42-49)
+    assert [(k, v.default) for k, v in sig.parameters.items()] == [
+        ("query", inspect.Parameter.empty), ("top_k", 10), ("symbol_boost", 2.0), ("include_documents", False),
+        ("collection_name", "code_chunks")]
+
+
+def test_http_request_model_defaults_and_limits_come_from_the_config():
+    from coderag_hip.http_app import make_search_request
+    import pydantic
+    R = make_search_request({"top_k": 7, "symbol_boost": 2.5})
+    r = R(query="x")
+    assert (r.top_k, r.symbol_boost) == (7, 2.5)
+    for bad in (0, -1, 201):
+        with pytest.raises(pydantic.ValidationError):
+            R(query="x", top_k=bad)
+    with pytest.raises(pydantic.ValidationError):
+        R(query="")                                         # api/main.py:144 min_length=1
+
+
+# ---- whole collections placed over several GPUs (last sentence) ----
+def test_collections_are_placed_round_robin_over_the_devices(monkeypatch):
+    import coderag_hip.hybrid_search as H
+
+    class FakeCol:
+        def __init__(self, name, dim, dtype, metric, device):
+            self.name, self.device = name, device
+
+    monkeypatch.setattr(H, "ChunkCollection", FakeCol)
+    hs = ch.HybridSearcher(db_path="unused", devices=[0, 1, 2, 3, 4, 5, 6, 7])
+    cols = [hs.create_collection(f"code_chunks__ws{i}", 384) for i in range(64)]
+    per_dev = {d: sum(1 for c in cols if c.device == d) for d in range(8)}
+    assert per_dev == {d: 8 for d in range(8)}              # 64 workspaces over 8 GPUs = 8 each
+    assert hs.create_collection("code_chunks__ws3", 384).device == cols[3].device   # fresh re-create stays put
+    assert hs.create_collection("code_chunks__pinned", 384, device=5).device == 5
+    assert ch.HybridSearcher(db_path="unused", device=2).devices == [2]
+
+
+def test_group_requests_one_launch_per_device_and_geometry():
+    k = lambda dev, name, dim=1024, dt="bf16": (dev, dim, dt, "l2", name)
+    keys = [k(0, "a"), k(1, "b"), None, k(0, "c"), k(0, "a"), k(1, "d"), k(1, "b"), k(0, "e", 384, "f32")]
+    groups = ch.group_requests(keys)
+    assert sorted(map(tuple, groups)) == [(0, 4, 3), (1, 6, 5), (7,)]   # same collection adjacent, one group per geometry
+    assert ch.group_requests([None, None]) == []
+    flat = sorted(i for g in groups for i in g)
+    assert flat == [0, 1, 3, 4, 5, 6, 7]                    # every live request exactly once

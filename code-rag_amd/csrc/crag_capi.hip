@@ -583,10 +583,22 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * (size_t)cand_stride))) return rc;
     cand = (unsigned long long*)ws->cand.p;
     uint32_t* segcnt = nullptr;
+    // pacing words of the two-block scan's filter levels when the batch has several query groups (B > 256): one
+    // zeroed block per level behind the segment counters (MfmaArgs::progress)
+    static const int ahead_max = [] {
+        const char* e = getenv("CRAG_AHEAD_MAX");  // tuning / A-B runs; 0 switches the pacing off
+        return e ? atoi(e) : 4;
+    }();
+    const bool paced = segmented && B > 256 && ahead_max > 0;
+    const size_t prog_words = paced ? (size_t)CRAG_PROGRESS_WORDS(h0->n_cus) : 0;
+    uint32_t* progress = nullptr;
     if (segmented) {
-        if ((rc = ws->segcnt.ensure(sizeof(uint32_t) * (size_t)B * (size_t)n_seg))) return rc;
+        const size_t seg_words = ((size_t)B * (size_t)n_seg + 31) / 32 * 32;  // keeps the pacing lines 128-byte aligned
+        const size_t words = seg_words + prog_words * CRAG_MAX_LEVELS;
+        if ((rc = ws->segcnt.ensure(sizeof(uint32_t) * words))) return rc;
         segcnt = (uint32_t*)ws->segcnt.p;
-        HIPCHK(hipMemsetAsync(segcnt, 0, sizeof(uint32_t) * (size_t)B * (size_t)n_seg, st));
+        if (paced) progress = segcnt + seg_words;
+        HIPCHK(hipMemsetAsync(segcnt, 0, sizeof(uint32_t) * words, st));
     }
 
     // ---- passes ----
@@ -612,6 +624,8 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         ma.seg_cap = seg_cap;
         ma.cand_stride = cand_stride;
         ma.row_begin = 0;
+        ma.progress = nullptr;
+        ma.ahead_max = ahead_max;
         h0->stats[5]++;
     } else {
         ga.groups = gd_dev;
@@ -679,6 +693,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
             }
             ma.row_begin = from;
             ma.row_end = nb[l];
+            ma.progress = paced ? progress + l * prog_words : nullptr;
             if (launch_level(1)) return fail(CRAG_E_HIP, "filter scan launch failed");
             if (last) {
                 if (prof) HIPCHK(hipEventRecord(ws->ev[3], st));

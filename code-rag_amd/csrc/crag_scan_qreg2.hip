@@ -23,6 +23,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8_t;
 
 constexpr int Q2_TM = 32;      // corpus rows per tile
 constexpr int Q2_WAVES = 4;    // waves per workgroup: one per SIMD
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                                                                  int nqg, int metric, const float* __restrict__ tau,
                                                                  uint32_t* __restrict__ sample, long long sample_stride,
                                                                  unsigned long long* __restrict__ cand,
-                                                                 uint32_t* __restrict__ segcnt, int n_seg, int seg_cap, long long cand_stride) {
+                                                                 uint32_t* __restrict__ segcnt, int n_seg, int seg_cap, long long cand_stride,
+                                                                 uint32_t* __restrict__ progress, int ahead_max) {
     constexpr int C = KS * 2;                  // 16-byte chunks per row
     constexpr int D = KS * 16;                 // elements per row
     constexpr int ROWB = C * 16;               // bytes per row (a multiple of 256)
@@ -126,6 +128,23 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
     const long long n_tiles = (row_end + Q2_TM - 1) / Q2_TM;
     const long long t_step = (long long)n_streams * 8;
     long long t = row_begin / Q2_TM + (long long)stream * 8 + xcd;  // row_begin: a multiple of the tile height
+
+    // PACING (launches with several query groups, MODE 1).  The nqg workgroups of one (xcd, stream) pair read the
+    // same tiles, and the XCD's L2 is what lets the second to the last reader find a tile the first one fetched --
+    // as long as they stay within a few tiles of each other (8 streams x 48 KiB tiles share 4 MiB).  Left alone
+    // they drift apart (the filter's slow path costs each query group differently) and the re-reads go to the
+    // Infinity Cache or HBM.  Each workgroup publishes its tile count (one sc1 store per tile), wave 0 reads the
+    // others' counts with one scalar load per tile inside its tile statement, and a workgroup more than ahead_max
+    // tiles ahead of the slowest waits for it.  Waiting costs nothing: the launch ends with its slowest workgroup.
+    // Speed only, never correctness: every wait is bounded (a partner that is not resident yet, or that another
+    // process keeps off the chip, ends the pacing for this workgroup), and a finished workgroup reports "infinitely far".
+    uint32_t* const prog = (MODE == 1 && !NT && nqg > 1 && progress) ? progress + (long long)(stream * 8 + xcd) * 32 : nullptr;
+    bool pacing = prog != nullptr && wave == 0;  // wave-uniform
+    // wave 0's statement always loads 32 bytes; without pacing from a line of this workgroup's own (every workgroup
+    // polling ONE line with scalar glc loads serialises in its L2 channel: the kernel ran 2.6x longer)
+    const unsigned* const pp = prog ? (const unsigned*)prog : (const unsigned*)(queries + (long long)(b % n_queries) * D);
+    unsigned tiles_done = 0;
+    u32x8_t pv;
 
     const int q_base = qg * Q2_QPB + wave * Q2_QPW;
     const bool wave_active = q_base < n_queries;  // wave-uniform
@@ -238,7 +257,10 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
                 d.xn = xnorm + nt2 * Q2_TM;
                 d.xn_dst = lds_base + XN_BASE + (nxt2 * Q2_WAVES + wave) * Q2_XN_BYTES;
                 switch (wave) {  // the DMA slots of the K-loop are staggered by wave
-                    case 0: Qreg2KLoop<KS, true, 0, NT>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
+                    case 0:
+                        if constexpr (NT) Qreg2KLoop<KS, true, 0, true>::run(acc0, acc1, xs, mn0, mn1, a0, e, d);
+                        else Qreg2KLoop<KS, true, 0, false>::run(acc0, acc1, xs, mn0, mn1, a0, e, d, pp, pv);
+                        break;
                     case 1: Qreg2KLoop<KS, true, 1, NT>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
                     case 2: Qreg2KLoop<KS, true, 2, NT>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
                     default: Qreg2KLoop<KS, true, 3, NT>::run(acc0, acc1, xs, mn0, mn1, a0, e, d); break;
@@ -294,6 +316,27 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if constexpr (MODE == 1 && !NT) {
+            if (pacing) {  // wave 0 of a workgroup that shares its tiles
+                ++tiles_done;
+                if (lane == 0) __hip_atomic_store(prog + qg, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dma_in_loop) {  // this tile's statement polled the partners (their counts as of its start)
+                    for (int spin = 0;; ++spin) {
+                        unsigned slowest = 0xffffffffu;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (i < nqg && i != qg) slowest = pv[i] < slowest ? pv[i] : slowest;
+                        if (tiles_done <= slowest + (unsigned)ahead_max) break;
+                        if (spin == 96) {  // ~150 us: the partner is not on the chip; stop pacing for good
+                            pacing = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(16);
+                        asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pv) : "s"(pp) : "memory");
+                    }
+                }
+            }
+        }
 #ifdef Q2_PROFILE
         const unsigned long long prof_b = Q2_PROF_NOW();
 #endif
@@ -309,6 +352,7 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
         if (ok0) segcnt[(long long)q0 * n_seg + seg] = pos0;
         if (ok1) segcnt[(long long)q1 * n_seg + seg] = pos1;
     }
+    if (prog && wave == 0 && lane == 0) __hip_atomic_store(prog + qg, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef Q2_PROFILE
     if (lane == 0) {
         uint32_t* pc = segcnt + Q2_PROFILE;  // tools/qreg_bench.hip: counters behind the segment counters
@@ -331,7 +375,7 @@ int launch_one(const MfmaArgs& a, int grid, int nqg, size_t lds, hipStream_t s) 
     crag_allow_dynamic_lds((const void*)k_scan_qreg2<KS, MODE, NT>, lds, lds_ok);
     hipLaunchKernelGGL((k_scan_qreg2<KS, MODE, NT>), dim3(grid), dim3(64 * Q2_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,
                        a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, nqg, a.metric, a.tau, a.sample,
-                       a.sample_stride, a.cand, a.segcnt, a.n_seg, a.seg_cap, a.cand_stride);
+                       a.sample_stride, a.cand, a.segcnt, a.n_seg, a.seg_cap, a.cand_stride, a.progress, a.ahead_max);
     return (int)hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include "../code-rag_amd/csrc/crag_scan_qreg2.hip"
 #define LAUNCH crag_launch_scan_qreg2
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <cstdlib>
 int main(int argc, char** argv) {
@@ -19,7 +20,7 @@ int main(int argc, char** argv) {
     hipMemset(xn, 0, (n + 512) * 4); hipMemset(cnt, 0, 4 * (1024 * 512 + 64));
     std::vector<float> t(1024, argc > 3 ? (float)atof(argv[3]) : -1e30f);  // argv[3]: tau (random corpus: score sigma ~ 6.7e-3)
     hipMemcpy(tau, t.data(), 4096, hipMemcpyHostToDevice);
-    MfmaArgs a; a.rows = rows; a.xnorm = xn; a.n_rows = n; a.row_begin = 0; a.row_end = n; a.queries = q; a.n_queries = B;
+    MfmaArgs a; memset(&a, 0, sizeof(a)); a.rows = rows; a.xnorm = xn; a.n_rows = n; a.row_begin = 0; a.row_end = n; a.queries = q; a.n_queries = B;
     a.dim_pad = D; a.metric = CRAG_L2; a.tau = tau; a.sample = nullptr; a.sample_stride = 0; a.cand = cand; a.cnt = cnt;
 #ifdef USE_Q2
     a.segcnt = cnt; a.n_seg = crag_qreg2_segments(B, 256); a.seg_cap = CRAG_CAND_CAP / a.n_seg; a.cand_stride = (long long)a.n_seg * a.seg_cap;

@@ -407,7 +407,46 @@ def extra_regimes(col, q, n, d, torch):
         if pe.get("mfma_busy_frac"):
             out[-1]["pmc_mfma_busy_frac"] = pe["mfma_busy_frac"]  # matrix pipe busy cycles / (SIMDs x kernel cycles)
     col.set_path("auto")
+    out.append(adversarial_regime(q, n, d, torch))
     return out
+
+
+def adversarial_regime(q, n, d, torch):
+    """The fallback under adversarial input: every vector of the corpus exists 3000 times and the 256 queries are
+    corpus vectors, so each query's 2*top_k nearest are decided by row id among 3000 exact ties and no certificate of
+    the first pass can hold: the WHOLE batch falls back.  (The certified re-scan settles it with one more pass over the
+    corpus; only more ties than a candidate buffer holds, 16384 per query, would need the full exact scan.)"""
+    import coderag_hip as ch
+    dev = q.device
+    nb = (n + 2999) // 3000
+    g = torch.Generator(device=dev).manual_seed(77)
+    base = torch.randn((nb, d), generator=g, device=dev, dtype=torch.float32)
+    base = (base / base.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    rows = torch.empty((n, d), dtype=torch.bfloat16, device=dev)
+    for lo in range(0, n, 1_000_000):
+        m = min(1_000_000, n - lo)
+        rows[lo:lo + m] = base[(torch.arange(lo, lo + m, device=dev) % nb)]
+    col = ch.GpuCollection(d, "bf16", "l2", device=dev.index)
+    col.attach_device(rows)
+    col.finalize()
+    qa = base[:256].contiguous()
+    res = col.search_device(qa, 10, 2.0)
+    col.stats(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 2
+    for _ in range(steps):
+        col.search_device(qa, 10, 2.0, out=res)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = col.stats(reset=True)
+    ids = res[0].cpu()
+    ok = bool((ids[:, 0] == torch.arange(256)).all() and (res[2].cpu() == 0).all())  # the first copies, distance 0
+    col.close()
+    return {"regime": f"adversarial ties: {nb} vectors x 3000 copies = {n} x {d} bf16, batch-256 top-10, every query falls back",
+            "queries_per_s": round(256 / dt, 2), "ms_per_batch": round(dt * 1e3, 2), "fallback_queries_per_batch": st["fallback"] // steps,
+            "settled_by_the_certified_rescan_per_batch": st["rescan"] // steps, "exact_scan_queries_per_batch": st["exact_scan"] // steps,
+            "answers_are_the_first_copies_at_distance_0": ok}
 
 
 def config_regimes(ch, torch, np, dev):

@@ -259,9 +259,9 @@ class GpuCollection:
         return entries
 
     def stats(self, reset: bool = False) -> dict:
-        a = np.zeros(7, np.int64)
+        a = np.zeros(9, np.int64)
         check(self._lib.crag_stats(self._h, a.ctypes.data, int(reset)))
-        keys = ["searches", "queries", "fallback", "uncertified", "overflow", "mfma_batches", "gemv_batches"]
+        keys = ["searches", "queries", "fallback", "uncertified", "overflow", "mfma_batches", "gemv_batches", "exact_scan", "rescan"]
         return dict(zip(keys, (int(x) for x in a)))
 
     def debug_dense_scores(self, queries, path: str = "gemv"):

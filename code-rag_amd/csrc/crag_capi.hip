@@ -241,7 +241,7 @@ struct crag_index {
     int profiling = 0;
     std::mutex prof_mu;
     double prof[4] = {0, 0, 0, 0};  // sample-scan ms, filter-scan ms, searches timed, rows the filter-pass launches scanned
-    std::atomic<long long> stats[7];
+    std::atomic<long long> stats[9];  // [7]: queries that needed the full exact scan (tier 2), [8]: the certified re-scan (tier 1b)
     crag_index() {
         for (auto& s : stats) s = 0;
     }
@@ -366,6 +366,36 @@ struct Plan {
     bool need_mid = false;
 };
 
+// GEMV work list: blocks of each group for one pass (0 dense sample, 1 level-1 filter, 2 full filter), shares of the
+// chip in proportion to the rows the pass scans for the group.  Fills blk_first / n_blk of the pass; returns the grid.
+int gemv_partition(SmallVec<GroupDesc, 64>& gd, int pass, int nq_template, int n_cus) {
+    const int RT = 64 / nq_template;
+    const long long max_waves = (long long)n_cus * 12;
+    auto rows_of = [&](const GroupDesc& g) {
+        if (pass == 0) return g.n_sample;
+        if (pass == 1) return g.n_mid > g.n_sample ? g.n_mid - g.from[1] : 0LL;  // level 1 only where it exists
+        return g.n_rows - g.from[2];
+    };
+    long long total_st = 0;
+    for (auto& g : gd) total_st += (rows_of(g) + RT - 1) / RT;
+    int blk = 0;
+    for (auto& g : gd) {
+        const long long stg = (rows_of(g) + RT - 1) / RT;
+        g.blk_first[pass] = blk;
+        if (stg == 0) {
+            g.n_blk[pass] = 0;
+            continue;
+        }
+        long long share = std::max<long long>(4, max_waves * stg / std::max<long long>(total_st, 1));
+        long long waves = std::min(stg, share);
+        const long long T = (stg + waves - 1) / waves;
+        waves = (stg + T - 1) / T;
+        g.n_blk[pass] = (int)((waves + 3) / 4);
+        blk += g.n_blk[pass];
+    }
+    return blk;
+}
+
 // where the single-GPU entry points want the reranked results (stage 2 launched optimistically right
 // behind stage 1, before the host looks at the certificates; re-launched if a fallback patched entries)
 struct MergeOut {
@@ -454,7 +484,9 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     // (tools/sweep_small_batch.py 384 f32: B = 16 2.45 vs 3.40 ms, B = 32 4.66 vs 3.44 ms on 4M rows).
     // Rows no query-stationary kernel takes (bf16 longer than 1024 elements, float32 longer than 384) stay on
     // the GEMV groups at every batch size.
-    const int mfma_from = can_qf32 ? 25 : (h0->dim_pad >= 768 ? 2 : 3);
+    // 1024-element rows: the split-K scan with nontemporal DMA is ahead of the GEMV even for ONE query (same box,
+    // 1M / 3M / 10M rows: 0.42 vs 0.46, 1.00 vs 1.13, 2.99 vs 3.42 ms); at 768 elements one query is a tie
+    const int mfma_from = can_qf32 ? 25 : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
     P.mfma = same_handle && (can_qreg || can_qsplit || can_qf32) && (path == 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
@@ -519,35 +551,10 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
             b = e;
         }
         P.nq_template = max_nq <= 1 ? 1 : (max_nq <= 2 ? 2 : (max_nq <= 4 ? 4 : 8));
-        const int RT = 64 / P.nq_template;
-        const long long max_waves = (long long)h0->n_cus * 12;
-        for (int pass = 0; pass < 3; ++pass) {
-            auto rows_of = [&](const GroupDesc& g) {
-                if (pass == 0) return g.n_sample;
-                if (pass == 1) return g.n_mid > g.n_sample ? g.n_mid - g.from[1] : 0LL;  // level 1 only where it exists
-                return g.n_rows - g.from[2];
-            };
-            long long total_st = 0;
-            for (auto& g : gd) total_st += (rows_of(g) + RT - 1) / RT;
-            int blk = 0;
-            for (auto& g : gd) {
-                const long long stg = (rows_of(g) + RT - 1) / RT;
-                g.blk_first[pass] = blk;
-                if (stg == 0) {
-                    g.n_blk[pass] = 0;
-                    continue;
-                }
-                long long share = std::max<long long>(4, max_waves * stg / std::max<long long>(total_st, 1));
-                long long waves = std::min(stg, share);
-                const long long T = (stg + waves - 1) / waves;
-                waves = (stg + T - 1) / T;
-                g.n_blk[pass] = (int)((waves + 3) / 4);
-                blk += g.n_blk[pass];
-            }
-            P.blocks[pass] = blk;
-        }
+        for (int pass = 0; pass < 3; ++pass) P.blocks[pass] = gemv_partition(gd, pass, P.nq_template, h0->n_cus);
     }
     P.n_groups = (int)gd.size();
+
 
     // ---- workspace ----
     const size_t desc_bytes = sizeof(QueryDesc) * (size_t)B + sizeof(GroupDesc) * gd.size();
@@ -792,6 +799,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     f.n_seg = n_seg;
     f.seg_cap = seg_cap;
     f.cand_stride = cand_stride;
+    f.qmap = nullptr;
     if ((rc = crag_launch_finalize(f, st))) return fail(CRAG_E_HIP, "finalize launch failed");
     auto merge = [&]() -> int {
         if (!mo) return 0;
@@ -816,74 +824,147 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     }
     h0->stats[0]++;
     h0->stats[1] += B;
+    // ---- fallback for the queries that came back without a certificate ----
+    SmallVec<int, 64> failed;
     for (int b = 0; b < B; ++b) {
         if (hst[(size_t)b] == CRAG_ST_OK) continue;
-        crag_index* h = hs[b];
         h0->stats[2]++;
         if (hst[(size_t)b] == CRAG_ST_UNCERTIFIED) h0->stats[3]++;
         if (hst[(size_t)b] == CRAG_ST_OVERFLOW) h0->stats[4]++;
+        failed.push_back(b);
+    }
+    if (!failed.empty()) {
         if (noalloc)  // the exact scan needs 8 bytes per row of the collection: not in a fixed scratch array
             return fail(CRAG_E_INEXACT, "crag_search_device_noalloc: a query failed its exactness certificate and needs the exact "
                                         "fallback scan (8 bytes of workspace per row); call crag_search_device for this batch");
-        // exact fallback: canonical float32 distance of every row, radix-select the kc smallest keys
-        const long long n = h->n_rows;
-        const int kc = (int)std::min<long long>(P.kc, n);
-        if ((rc = ws->keys.ensure(sizeof(unsigned long long) * (size_t)std::max<long long>(n, 1)))) return rc;
-        if ((rc = ws->misc.ensure(4096))) return rc;
-        unsigned long long* keys = (unsigned long long*)ws->keys.p;
-        unsigned int* hist = (unsigned int*)ws->misc.p;
-        const void* qv = (const char*)q_dev + (size_t)b * h->dim_pad * h->esz;
-        if ((rc = crag_launch_exact_keys(&qd[(size_t)b], qv, h->dtype, h->dim, h->dim_pad, h->metric, keys, st)))
-            return fail(CRAG_E_HIP, "exact_keys launch failed");
-        unsigned long long prefix = 0, mask = 0;
-        unsigned int want = (unsigned int)kc;
-        for (int shift = 56; shift >= 0 && kc > 0; shift -= 8) {
-            unsigned int hh[256];
-            HIPCHK(hipMemsetAsync(hist, 0, 1024, st));
-            if ((rc = crag_launch_hist64(keys, n, prefix, mask, shift, hist, st))) return fail(CRAG_E_HIP, "hist64 launch failed");
-            HIPCHK(hipMemcpyAsync(hh, hist, 1024, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            unsigned int cum = 0;
-            int bin = 255;
-            for (int i = 0; i < 256; ++i) {
-                if (cum + hh[i] >= want) {
-                    bin = i;
-                    break;
+        // device list of the failed queries (tier 1 takes the uncertified ones first, tier 2 whatever is left)
+        const size_t nf = failed.size();
+        if ((rc = ws->ensure_pinned(sizeof(int) * nf))) return rc;
+        if ((rc = ws->misc.ensure(sizeof(int) * nf + 256))) return rc;
+        int* qmap_dev = (int*)ws->misc.p;
+        auto upload_qmap = [&](const SmallVec<int, 64>& v) -> int {
+            memcpy(ws->pinned, v.data(), sizeof(int) * v.size());
+            HIPCHK(hipMemcpyAsync(qmap_dev, ws->pinned, sizeof(int) * v.size(), hipMemcpyHostToDevice, st));
+            return 0;
+        };
+        // tier 1: the buffer of an uncertified query holds EVERY row with approximate score <= tau; re-score all of
+        // it exactly (not just the M best) and certify against tau alone.  Covers duplicated chunks and near-ties
+        // beyond the slack at the cost of a few thousand row reads per query.
+        SmallVec<int, 64> t1;
+        for (int b : failed)
+            if (hst[(size_t)b] == CRAG_ST_UNCERTIFIED) t1.push_back(b);
+        if (!t1.empty()) {
+            if ((rc = upload_qmap(t1))) return rc;
+            FinalizeArgs g = f;
+            g.qmap = qmap_dev;
+            g.B = (int)t1.size();
+            g.trusted = 2;
+            if (crag_launch_rescore_wide(g, (unsigned long long*)ws->cand.p, g.B, st)) return fail(CRAG_E_HIP, "wide re-score launch failed");
+            if ((rc = crag_launch_finalize(g, st))) return fail(CRAG_E_HIP, "tier-1 finalize launch failed");
+            if (noalloc) HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
+            HIPCHK(stream_wait(st));
+            patched = true;
+        }
+        // tier 1b: certified re-scan.  The kc exact distances a failed query already has bound its true kc-th nearest
+        // from above; one more pass over ALL rows with a threshold derived from that bound collects every row that
+        // can enter or tie into the result, and re-scoring all of them exactly settles it.  One scan for the whole
+        // batch (the queries that were fine append nothing), whatever the number of ties -- unless more than the
+        // buffer holds (16384) lie within the float32 error of the boundary, which is left to tier 2.
+        SmallVec<int, 64> t1b;
+        for (int b : failed)
+            if (hst[(size_t)b] != CRAG_ST_OK) t1b.push_back(b);
+        if (!t1b.empty()) {
+            FinalizeArgs r = f;  // a.status: the pinned certificates, readable from the device
+            if (crag_launch_tau_refine(r, tau, cnt, segcnt, st)) return fail(CRAG_E_HIP, "tau refine launch failed");
+            if (P.mfma) {
+                ma.row_begin = 0;
+                ma.row_end = h0->n_rows;
+                ma.progress = nullptr;
+                if (segmented ? crag_launch_scan_qreg2(ma, 1, h0->n_cus, st)
+                    : qsplit  ? crag_launch_scan_qsplit(ma, 1, h0->n_cus, st)
+                              : crag_launch_scan_qf32(ma, 1, h0->n_cus, st))
+                    return fail(CRAG_E_HIP, "re-scan launch failed");
+            } else {
+                // the same groups over all of their rows: descriptors with from[2] = 0 behind the first set
+                SmallVec<GroupDesc, 64> gd2;
+                for (const auto& g : gd) {
+                    gd2.push_back(g);
+                    gd2.back().from[2] = 0;
                 }
-                cum += hh[i];
+                const int blocks2 = gemv_partition(gd2, 2, P.nq_template, h0->n_cus);
+                const size_t bytes2 = sizeof(GroupDesc) * gd2.size();
+                if ((rc = ws->ensure_pinned(bytes2))) return rc;
+                if ((rc = ws->keys.ensure(bytes2))) return rc;
+                memcpy(ws->pinned, gd2.data(), bytes2);
+                HIPCHK(hipMemcpyAsync(ws->keys.p, ws->pinned, bytes2, hipMemcpyHostToDevice, st));
+                ScanArgs ga2 = ga;
+                ga2.groups = (const GroupDesc*)ws->keys.p;
+                if (crag_launch_scan_gemv(ga2, 2, P.nq_template, blocks2, st)) return fail(CRAG_E_HIP, "re-scan launch failed");
             }
-            want -= cum;
-            prefix |= (unsigned long long)bin << shift;
-            mask |= 0xffull << shift;
+            HIPCHK(hipStreamSynchronize(st));  // the pinned staging (descriptors, then the query list) is reused below
+            if ((rc = upload_qmap(t1b))) return rc;
+            FinalizeArgs g = f;
+            g.qmap = qmap_dev;
+            g.B = (int)t1b.size();
+            g.trusted = 2;
+            if (crag_launch_rescore_wide(g, (unsigned long long*)ws->cand.p, g.B, st)) return fail(CRAG_E_HIP, "wide re-score launch failed");
+            if ((rc = crag_launch_finalize(g, st))) return fail(CRAG_E_HIP, "tier-1b finalize launch failed");
+            HIPCHK(stream_wait(st));
+            h0->stats[8] += (long long)t1b.size();
+            patched = true;
         }
-        unsigned long long* cq = (unsigned long long*)ws->cand.p + (size_t)b * CRAG_CAND_CAP;
-        HIPCHK(hipMemsetAsync(cnt + CRAG_CNT(b), 0, 4, st));
-        if (kc > 0) {
-            if ((rc = crag_launch_gather_le(keys, n, prefix, cq, cnt + CRAG_CNT(b), CRAG_CAND_CAP, st)))
-                return fail(CRAG_E_HIP, "gather launch failed");
+        // tier 2: canonical distance of every row + radix select on the device, batched (chunks bounded by 2 GiB of keys)
+        SmallVec<int, 64> t2;
+        long long n_max = 0;
+        for (int b : failed)
+            if (hst[(size_t)b] != CRAG_ST_OK) {
+                t2.push_back(b);
+                n_max = std::max<long long>(n_max, hs[b]->n_rows);
+            }
+        h0->stats[7] += (long long)t2.size();
+        if (!t2.empty()) {
+            const long long key_stride = (std::max<long long>(n_max, 1) + 255) / 256 * 256;
+            const size_t per_chunk = (size_t)std::max<long long>(1, std::min<long long>((long long)t2.size(), (2ll << 30) / (8 * key_stride)));
+            if ((rc = ws->keys.ensure(sizeof(unsigned long long) * per_chunk * (size_t)key_stride))) return rc;
+            const size_t qmap_bytes = (sizeof(int) * t2.size() + 255) / 256 * 256;
+            if ((rc = ws->misc.ensure(qmap_bytes + per_chunk * (256 * sizeof(unsigned int) + sizeof(CragRadixState))))) return rc;
+            qmap_dev = (int*)ws->misc.p;
+            if ((rc = upload_qmap(t2))) return rc;
+            for (size_t c0 = 0; c0 < t2.size(); c0 += per_chunk) {
+                ExactSelectArgs e;
+                e.qd = qd_dev;
+                e.qmap = qmap_dev + c0;
+                e.F = (int)std::min(per_chunk, t2.size() - c0);
+                e.queries = q_dev;
+                e.dtype = h0->dtype;
+                e.dim = h0->dim;
+                e.dim_pad = h0->dim_pad;
+                e.metric = h0->metric;
+                e.kc = P.kc;
+                e.n_max = n_max;
+                e.keys = (unsigned long long*)ws->keys.p;
+                e.key_stride = key_stride;
+                e.hist = (unsigned int*)((char*)ws->misc.p + qmap_bytes);
+                e.state = (CragRadixState*)(e.hist + per_chunk * 256);
+                e.cand = (unsigned long long*)ws->cand.p;
+                e.cand_stride = cand_stride;
+                e.cnt = cnt;
+                if (crag_launch_exact_select(e, st)) return fail(CRAG_E_HIP, "exact fallback launch failed");
+                FinalizeArgs g = f;
+                g.qmap = e.qmap;
+                g.B = e.F;
+                g.M = std::max(P.kc, 1);
+                g.trusted = 1;
+                g.segcnt = nullptr;  // the gather fills the flat view of each query's slots
+                g.n_seg = 0;
+                g.seg_cap = 0;
+                if ((rc = crag_launch_finalize(g, st))) return fail(CRAG_E_HIP, "fallback finalize launch failed");
+            }
+            HIPCHK(stream_wait(st));
+            for (int b : t2)
+                if (hst[(size_t)b] != CRAG_ST_OK) return fail(CRAG_E_HIP, "exact fallback did not produce a certified result");
+            patched = true;
         }
-        FinalizeArgs g = f;
-        g.qd = qd_dev + b;
-        g.queries = qv;
-        g.B = 1;
-        g.M = std::max(kc, 1);
-        g.cand = cq;
-        g.cnt = cnt + CRAG_CNT(b);
-        g.tau = (const float*)ws->tau.p + b;
-        g.trusted = 1;
-        g.segcnt = nullptr;  // the fallback's gather fills the flat buffer
-        g.n_seg = 0;
-        g.seg_cap = 0;
-        g.cand_stride = CRAG_CAND_CAP;
-        g.qhash_off = qhoff_dev ? (const int*)qhoff_dev + b : nullptr;
-        g.entries = entries_dev + (size_t)b * P.kc;
-        g.status = status + b;
-        if ((rc = crag_launch_finalize(g, st))) return fail(CRAG_E_HIP, "fallback finalize launch failed");
-        uint32_t s2 = 1;
-        HIPCHK(hipMemcpyAsync(&s2, status + b, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (s2 != CRAG_ST_OK) return fail(CRAG_E_HIP, "exact fallback did not produce a certified result");
-        patched = true;
     }
     if (patched && merge()) return fail(CRAG_E_HIP, "merge_rerank launch failed");
     return 0;
@@ -1384,10 +1465,10 @@ int crag_search_multi_device(crag_index* const* hs, const void* queries_dev, int
     return 0;
 }
 
-int crag_stats(crag_index* h, int64_t* out7, int reset) {
-    if (!h || !out7) return fail(CRAG_E_INVALID, "crag_stats: bad arguments");
-    for (int i = 0; i < 7; ++i) {
-        out7[i] = h->stats[i];
+int crag_stats(crag_index* h, int64_t* out9, int reset) {
+    if (!h || !out9) return fail(CRAG_E_INVALID, "crag_stats: bad arguments");
+    for (int i = 0; i < 9; ++i) {
+        out9[i] = h->stats[i];
         if (reset) h->stats[i] = 0;
     }
     return 0;

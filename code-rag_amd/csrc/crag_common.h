@@ -189,17 +189,39 @@ struct FinalizeArgs {
     const uint32_t* segcnt;           // segmented candidate buffer (see MfmaArgs) when n_seg > 0; then cnt is unused
     int n_seg, seg_cap;
     long long cand_stride;            // slots per query in cand (CRAG_CAND_CAP when flat)
+    const int* qmap;                  // null: block b serves query b; else block b serves query qmap[b] (fallback passes)
 };
 int crag_launch_finalize(const FinalizeArgs& a, hipStream_t s);
 int crag_launch_merge_rerank(const CragEntry* entries, int G, int B, int kc, int top_k, double symbol_boost,
                              long long* out_ids, double* out_scores, float* out_dist, int* out_counts,
                              hipStream_t s);
-int crag_launch_exact_keys(const QueryDesc* qd_host, const void* query, int dtype, int dim, int dim_pad, int metric,
-                           unsigned long long* keys, hipStream_t s);
-int crag_launch_hist64(const unsigned long long* keys, long long n, unsigned long long prefix,
-                       unsigned long long mask, int shift, unsigned int* hist256, hipStream_t s);
-int crag_launch_gather_le(const unsigned long long* keys, long long n, unsigned long long thr,
-                          unsigned long long* out, unsigned int* out_cnt, unsigned int cap, hipStream_t s);
+// fallback tier 1b: per query of the batch (a.B, a.status readable from the device) the re-scan threshold; clears the
+// failed queries' candidate counters (segcnt may be null)
+int crag_launch_tau_refine(const FinalizeArgs& a, float* tau, unsigned int* cnt, uint32_t* segcnt, hipStream_t s);
+// fallback tier 1: every buffered candidate of the a.qmap[0 .. n_failed) queries re-scored exactly, keys rewritten in place
+int crag_launch_rescore_wide(const FinalizeArgs& a, unsigned long long* cand_rw, int n_failed, hipStream_t s);
+// fallback tier 2: exact keys of every row for F queries, radix select of the min(kc, n) smallest per query on the
+// device (no host round trips), gathered into the queries' flat candidate buffers (cnt must be zero for them)
+struct CragRadixState {
+    unsigned long long prefix, mask;
+    unsigned int want, pad;
+};
+struct ExactSelectArgs {
+    const QueryDesc* qd;   // device, whole batch
+    const int* qmap;       // device, [F] query numbers
+    int F;
+    const void* queries;   // device, whole batch, stride dim_pad
+    int dtype, dim, dim_pad, metric, kc;
+    long long n_max;       // most rows among the F queries' collections
+    unsigned long long* keys;  // [F][key_stride]
+    long long key_stride;
+    CragRadixState* state;     // [F]
+    unsigned int* hist;        // [F][256]
+    unsigned long long* cand;
+    long long cand_stride;
+    unsigned int* cnt;
+};
+int crag_launch_exact_select(const ExactSelectArgs& a, hipStream_t s);
 
 // Kernels that take more than 64 KiB of dynamic LDS opt in once per (kernel, device): the attribute belongs
 // to the device that is current, and one process may hold collections on several devices.  `done` is the

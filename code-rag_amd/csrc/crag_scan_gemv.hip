@@ -95,19 +95,23 @@ __device__ __forceinline__ float butterfly64(float (&v)[64], int lane) {
     return keep + dpp_mov<0xB1>(send);  // xor 1 (quad_perm [1,0,3,2])
 }
 
-// corpus rows are read once per pass by one wave: nontemporal loads (global_load_dwordx4 ... nt) keep them from
-// displacing what the L2 is for (queries, |x|^2, descriptors)
+// Corpus rows are read once per pass by one wave: nontemporal loads (global_load_dwordx4 ... nt) keep them from
+// displacing what the L2 is for (queries, |x|^2, descriptors).  Same box, 10M rows, one query: 256 / 384 / 512 / 768
+// bf16 elements per row +9 / +12 / +9 / +12 % bandwidth (6.18 -> 6.92 TB/s at 768), but 1024 elements (2-KiB rows, 128-KiB
+// super-tiles: every wave's stream a power-of-two stride from its neighbours') -16 %, so rows of 128 chunks and more
+// keep the default policy.
 #ifndef CRAG_GEMV_NT
 #define CRAG_GEMV_NT 1
 #endif
+template <bool NT>
 __device__ __forceinline__ uint4 load_row_chunk(const uint4* p) {
-#if CRAG_GEMV_NT
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-    const u32x4_t v = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4_t*)p);  // global, not flat
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
+    if constexpr (NT) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+        const u32x4_t v = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4_t*)p);  // global, not flat
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
 }
 
 template <int DT, int C, int NQ>
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     constexpr int RT = 64 / NQ;               // rows per super-tile
     constexpr int NL = RT * C / 64;           // wave loads per super-tile
     constexpr int U = NL < 6 ? NL : 6;        // loads in flight per wave
+    constexpr bool NT = CRAG_GEMV_NT && C < 128;
     static_assert(RT % PR == 0, "super-tile must hold whole periods");
     static_assert(C >= 32, "a wave load may span at most two rows");
 
@@ -180,14 +185,14 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
 #pragma unroll
         for (int n = 0; n < U; ++n) {
             const int rel = 64 * n + lane;
-            buf[n] = load_row_chunk(base + (rel < rel_max ? rel : rel_max));
+            buf[n] = load_row_chunk<NT>(base + (rel < rel_max ? rel : rel_max));
         }
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
             const uint4 x = buf[n % U];
             if (n + U < NL) {
                 const int rel = 64 * (n + U) + lane;
-                buf[n % U] = load_row_chunk(base + (rel < rel_max ? rel : rel_max));
+                buf[n % U] = load_row_chunk<NT>(base + (rel < rel_max ? rel : rel_max));
             }
             const int row_lo = (64 * n) / C;
             const int row_hi = (64 * n + 63) / C;

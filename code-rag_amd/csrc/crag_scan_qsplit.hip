@@ -240,7 +240,11 @@ int launch_one(const MfmaArgs& a, int grid, int nqg, hipStream_t s) {
 
 int launch_mode(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
     if (mode == 0) return launch_one<0, false>(a, grid, nqg, s);
+#ifdef CRAG_QSPLIT_NO_NT
+    return launch_one<1, false>(a, grid, nqg, s);
+#else
     return nqg == 1 ? launch_one<1, true>(a, grid, nqg, s) : launch_one<1, false>(a, grid, nqg, s);
+#endif
 }
 
 }  // namespace

@@ -8,7 +8,11 @@
 //   k_merge_rerank  per query: merge G shards' entries by (float32 distance, id), then
 //                   hybrid_search.py:82-125 verbatim in fp64 (base score, path/symbol boost,
 //                   strict > 0.01 filter, stable descending sort, truncate to top_k)
-//   k_exact_keys / k_hist64 / k_gather_le   the exact fallback scan (rare; correctness only)
+//   k_rescore_wide                          fallback tier 1: a query whose certificate failed gets EVERY buffered
+//                                           candidate re-scored exactly (duplicated chunks, near-ties beyond the slack)
+//   k_exact_keys_b / k_hist64_b / k_radix_pick / k_gather_le_b
+//                                           fallback tier 2: canonical distance of every row + radix select, batched
+//                                           over the failed queries, no host round trip between the passes
 #include "crag_common.h"
 
 namespace {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     uint32_t* sel_scratch = (uint32_t*)(red + 16);                                    // [KTH_SCRATCH]
     uint32_t* sel_count = sel_scratch + KTH_SCRATCH;                                  // [4]
     uint32_t* seg_off = sel_count + 4;                                                // [1024 + 1] segment offsets
-    const int q = blockIdx.x;
+    const int q = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x;  // fallback passes run on a subset of the batch
     const QueryDesc D = a.qd[q];
     const int tid = threadIdx.x;
     unsigned int status = CRAG_ST_OK;
@@ -527,9 +531,12 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
     // s_M + offset - eps.  If the kc-th exact float32 distance is strictly below the float32
     // rounding of that bound, no such row can enter (or tie into) the kc nearest.
     if (tid == 0) {
-        if (!a.trusted && status == CRAG_ST_OK && (long long)m < D.n_rows && kc_valid > 0) {
+        // trusted == 1: the keys are exact and the buffer provably holds the kc nearest (tier 2): nothing to certify.
+        // trusted == 2: the keys are exact but the buffer is still only "every row with approximate score <= tau"
+        // (tier 1): the order inside the buffer is exact, what remains to certify is the rows OUTSIDE it.
+        if (a.trusted != 1 && status == CRAG_ST_OK && (long long)(a.trusted == 2 ? c : m) < D.n_rows && kc_valid > 0) {
             // tightest known lower bound on the approximate score of every row not re-scored
-            const double sM = m < c ? (double)crag_fkey_inv((uint32_t)(skeys[m] >> 32)) : (double)a.tau[q];
+            const double sM = (m < c && a.trusted == 0) ? (double)crag_fkey_inv((uint32_t)(skeys[m] >> 32)) : (double)a.tau[q];
             const double u = 5.9604644775390625e-08;  // 2^-24
             const double X = (double)D.max_xnorm;
             const double qx = sqrt(qn * X);
@@ -634,60 +641,234 @@ __global__ __launch_bounds__(256) void k_merge_rerank(const CragEntry* __restric
 }
 
 // ----------------------------------------------------------------------------------------
-// exact fallback: canonical float32 distance of EVERY row (one thread per row), as 64-bit keys
-__global__ __launch_bounds__(256) void k_exact_keys(const void* __restrict__ rows, long long n,
-                                                    const void* __restrict__ query, int dtype, int dim, int dim_pad,
-                                                    int metric, unsigned long long* __restrict__ keys) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// Fallback tier 1.  One workgroup per failed query: every buffered candidate (all rows whose approximate score is
+// <= tau) gets its canonical float32 distance, 8 lanes per candidate, and its key is rewritten IN PLACE as
+// (exact distance key << 32 | row).  k_finalize then runs on these queries with trusted = 2.
+__global__ __launch_bounds__(1024) void k_rescore_wide(FinalizeArgs a, unsigned long long* __restrict__ cand_rw) {
+    __shared__ uint32_t seg_off[1024 + 1];
+    __shared__ uint32_t wsum[16];
+    const int q = a.qmap[blockIdx.x];
+    const QueryDesc D = a.qd[q];
+    const int tid = threadIdx.x;
+    const bool seg = a.n_seg > 0;
+    int c;
+    if (seg) {
+        bool ov;
+        c = block_seg_offsets(a.segcnt + (long long)q * a.n_seg, a.n_seg, a.seg_cap, seg_off, wsum, &ov);
+    } else {
+        c = (int)a.cnt[CRAG_CNT(q)];
+    }
+    if (c > CRAG_CAND_CAP) c = CRAG_CAND_CAP;  // (an overflowed query goes to tier 2 anyway)
+    unsigned long long* __restrict__ cq = cand_rw + (long long)q * a.cand_stride;
+    const size_t esz = a.dtype == CRAG_F32 ? 4 : 2;
+    const void* qv = (const char*)a.queries + (size_t)q * a.dim_pad * esz;
+    const int j = tid & 7;
+    for (int i0 = 0; i0 < c; i0 += 128) {  // the trip count is block-uniform: combine8 shuffles among all lanes
+        const int i = i0 + (tid >> 3);
+        int slot = 0;
+        uint32_t row = 0;
+        double acc = 0.0;
+        if (i < c) {
+            slot = seg ? seg_slot(seg_off, a.n_seg, a.seg_cap, i) : i;
+            row = (uint32_t)(cq[slot] & 0xffffffffull);
+            acc = canon_lane(D.rows, qv, a.dtype, a.dim, j, a.metric, (long long)row * a.dim_pad);
+        }
+        acc = combine8(acc);
+        if (i < c && j == 0) {
+            const double dist = a.metric == CRAG_L2 ? acc : __dsub_rn(1.0, acc);
+            cq[slot] = ((unsigned long long)crag_fkey((float)dist) << 32) | row;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Fallback tier 1b: thresholds for a CERTIFIED RE-SCAN.  A failed query still has kc exact distances in its entries
+// (of a subset of the rows), so d0 = the largest of them bounds the true kc-th nearest distance from above.  Every row
+// that can enter or tie into the result has exact distance <= d0, hence approximate score <= d0 - |q|^2 + eps; the
+// re-scan collects every row at or below tau' = that bound plus a few float32 steps of margin, and re-scoring ALL of
+// them exactly settles the query (k_finalize with trusted = 2 certifies against tau').  Queries that were fine get
+// tau = -inf: the re-scan appends nothing for them.  One block per query of the batch; clears the failed queries'
+// candidate counters.
+__global__ __launch_bounds__(256) void k_tau_refine(FinalizeArgs a, float* __restrict__ tau, unsigned int* __restrict__ cnt,
+                                                    uint32_t* __restrict__ segcnt) {
+    __shared__ double red[4];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (a.status[q] == CRAG_ST_OK) {
+        if (tid == 0) tau[q] = -__builtin_inff();
+        return;
+    }
+    const QueryDesc D = a.qd[q];
+    const size_t esz = a.dtype == CRAG_F32 ? 4 : 2;
+    const void* qv = (const char*)a.queries + (size_t)q * a.dim_pad * esz;
+    double part = 0.0;
+    for (int d = tid; d < a.dim; d += 256) {
+        const double v = load_elem_f64(qv, a.dtype, d);
+        part += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        const double qn = red[0] + red[1] + red[2] + red[3];
+        float d0 = a.entries[(long long)q * a.kc + a.kc - 1].dist;  // +inf when fewer than kc rows were found: no bound
+        for (int i = 0; i < 4; ++i) d0 = nextafterf(d0, __builtin_inff());  // a float32 tie with d0 must be collected too
+        const double u = 5.9604644775390625e-08;  // 2^-24
+        const double X = (double)D.max_xnorm;
+        const double qx = sqrt(qn * X);
+        double t;
+        if (a.metric == CRAG_L2) {
+            const double eps = 2.0 * u * (2.0 * (double)(a.dim_pad + 4) * qx + 3.0 * X + 1e-30);
+            t = (double)d0 - qn + 1.01 * eps + 2e-12 * (qn + X);
+        } else {
+            const double eps = 2.0 * u * ((double)(a.dim_pad + 4) * qx + 1e-30);
+            t = (double)d0 - 1.0 + 1.01 * eps + 2e-12 * (1.0 + qx);
+        }
+        float tf = (float)t;
+        if ((double)tf < t) tf = nextafterf(tf, __builtin_inff());
+        tau[q] = tf;
+        cnt[CRAG_CNT(q)] = 0;
+    }
+    if (segcnt)
+        for (int i = tid; i < a.n_seg; i += 256) segcnt[(long long)q * a.n_seg + i] = 0;
+}
+
+// ----------------------------------------------------------------------------------------
+// Fallback tier 2, batched over F failed queries (f = blockIdx.x % F runs fastest, so the workgroups that read one
+// block of rows for different queries are dispatched together and share it through the L2).
+// keys[f][row] = (canonical float32 distance key << 32 | row), one thread per (row, query).
+__global__ __launch_bounds__(256) void k_exact_keys_b(const QueryDesc* __restrict__ qd, const int* __restrict__ qmap, int F,
+                                                      const void* __restrict__ queries, int dtype, int dim, int dim_pad,
+                                                      int metric, unsigned long long* __restrict__ keys, long long key_stride) {
+    const int f = blockIdx.x % F;
+    const long long r = (long long)(blockIdx.x / F) * blockDim.x + threadIdx.x;
+    const int q = qmap[f];
+    const long long n = qd[q].n_rows;
     if (r >= n) return;
+    const void* __restrict__ rows = qd[q].rows;
+    const size_t esz = dtype == CRAG_F32 ? 4 : 2;
+    const void* query = (const char*)queries + (size_t)q * dim_pad * esz;  // staged: stride dim_pad, zero-padded
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long off = r * dim_pad;
+    // eight elements per step through 16-byte loads (rows and staged queries are zero-padded to dim_pad, a multiple of
+    // eight elements, and a padded element adds +0.0, which changes no partial sum)
+    const uint4* __restrict__ rv = (const uint4*)((const char*)rows + (size_t)r * dim_pad * esz);
+    const uint4* __restrict__ qv4 = (const uint4*)query;
     for (int d0 = 0; d0 < dim; d0 += 8) {
+        double x[8], y[8];
+        if (dtype == CRAG_F32) {
+            const uint4 a0 = qv4[d0 >> 2], a1 = qv4[(d0 >> 2) + 1], b0 = rv[d0 >> 2], b1 = rv[(d0 >> 2) + 1];
+            const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[j] = (double)__builtin_bit_cast(float, aw[j]);
+                y[j] = (double)__builtin_bit_cast(float, bw[j]);
+            }
+        } else {
+            const uint4 a0 = qv4[d0 >> 3], b0 = rv[d0 >> 3];
+            const uint32_t aw[4] = {a0.x, a0.y, a0.z, a0.w}, bw[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[2 * j] = (double)__builtin_bit_cast(float, aw[j] << 16);
+                x[2 * j + 1] = (double)__builtin_bit_cast(float, aw[j] & 0xffff0000u);
+                y[2 * j] = (double)__builtin_bit_cast(float, bw[j] << 16);
+                y[2 * j + 1] = (double)__builtin_bit_cast(float, bw[j] & 0xffff0000u);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int d = d0 + j;
-            if (d < dim) {
-                const double a = load_elem_f64(query, dtype, d);
-                const double b = load_elem_f64(rows, dtype, off + d);
-                double p;
-                if (metric == CRAG_L2) {
-                    const double t = __dsub_rn(a, b);
-                    p = __dmul_rn(t, t);
-                } else {
-                    p = __dmul_rn(a, b);
-                }
-                acc[j] = __dadd_rn(acc[j], p);
+            double p;
+            if (metric == CRAG_L2) {
+                const double t = __dsub_rn(x[j], y[j]);
+                p = __dmul_rn(t, t);
+            } else {
+                p = __dmul_rn(x[j], y[j]);
             }
+            acc[j] = __dadd_rn(acc[j], p);
         }
     }
     double s = __dadd_rn(__dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3])),
                          __dadd_rn(__dadd_rn(acc[4], acc[5]), __dadd_rn(acc[6], acc[7])));
     if (metric == CRAG_IP) s = __dsub_rn(1.0, s);
-    keys[r] = ((unsigned long long)crag_fkey((float)s) << 32) | (unsigned long long)(uint32_t)r;
+    keys[(long long)f * key_stride + r] = ((unsigned long long)crag_fkey((float)s) << 32) | (unsigned long long)(uint32_t)r;
 }
 
-__global__ __launch_bounds__(256) void k_hist64(const unsigned long long* __restrict__ keys, long long n,
-                                                unsigned long long prefix, unsigned long long mask, int shift,
-                                                unsigned int* __restrict__ hist) {
+// radix select of the want-th smallest 64-bit key per query, 8 bits per pass, state on the device
+__global__ __launch_bounds__(256) void k_radix_init(const QueryDesc* __restrict__ qd, const int* __restrict__ qmap, int kc,
+                                                    CragRadixState* __restrict__ st, unsigned int* __restrict__ hist,
+                                                    unsigned int* __restrict__ cnt) {
+    const int f = blockIdx.x;
+    hist[f * 256 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        cnt[CRAG_CNT(qmap[f])] = 0;  // the gather refills this query's flat buffer from slot 0
+        const long long n = qd[qmap[f]].n_rows;
+        st[f].prefix = 0;
+        st[f].mask = 0;
+        st[f].want = (unsigned int)(n < kc ? n : kc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hist64_b(const unsigned long long* __restrict__ keys, long long key_stride,
+                                                  const QueryDesc* __restrict__ qd, const int* __restrict__ qmap,
+                                                  const CragRadixState* __restrict__ st, int shift, unsigned int* __restrict__ hist) {
     __shared__ unsigned int h[256];
+    const int f = blockIdx.y;
+    const long long n = qd[qmap[f]].n_rows;
+    const unsigned long long prefix = st[f].prefix, mask = st[f].mask;
+    const unsigned long long* __restrict__ k0 = keys + (long long)f * key_stride;
     h[threadIdx.x] = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i];
+        const unsigned long long k = k0[i];
         if ((k & mask) == prefix) atomicAdd(&h[(unsigned int)(k >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x]) atomicAdd(&hist[f * 256 + threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void k_gather_le(const unsigned long long* __restrict__ keys, long long n,
-                                                   unsigned long long thr, unsigned long long* __restrict__ out,
-                                                   unsigned int* __restrict__ out_cnt, unsigned int cap) {
+// one block per query: the bin that holds the want-th smallest matching key joins the prefix; hist is cleared for the next pass
+__global__ __launch_bounds__(256) void k_radix_pick(CragRadixState* __restrict__ st, int shift, unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[256];
+    const int f = blockIdx.x;
+    h[threadIdx.x] = hist[f * 256 + threadIdx.x];
+    hist[f * 256 + threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int want = st[f].want, cum = 0;
+        if (want > 0) {
+            int bin = 255;
+            for (int i = 0; i < 256; ++i) {
+                if (cum + h[i] >= want) {
+                    bin = i;
+                    break;
+                }
+                cum += h[i];
+            }
+            st[f].want = want - cum;
+            st[f].prefix |= (unsigned long long)bin << shift;
+            st[f].mask |= 0xffull << shift;
+        }
+    }
+}
+
+// the keys <= the selected threshold (exactly min(kc, n) of them: keys are unique) into the query's flat buffer
+__global__ __launch_bounds__(256) void k_gather_le_b(const unsigned long long* __restrict__ keys, long long key_stride,
+                                                     const QueryDesc* __restrict__ qd, const int* __restrict__ qmap,
+                                                     const CragRadixState* __restrict__ st, unsigned long long* __restrict__ cand,
+                                                     long long cand_stride, unsigned int* __restrict__ cnt) {
+    const int f = blockIdx.y;
+    const int q = qmap[f];
+    const long long n = qd[q].n_rows;
+    if (st[f].mask == 0) return;  // an empty collection: nothing selected
+    const unsigned long long thr = st[f].prefix;
+    const unsigned long long* __restrict__ k0 = keys + (long long)f * key_stride;
+    unsigned long long* __restrict__ out = cand + (long long)q * cand_stride;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i];
+        const unsigned long long k = k0[i];
         if (k <= thr) {
-            const unsigned int pos = atomicAdd(out_cnt, 1u);
-            if (pos < cap) out[pos] = k;
+            const unsigned int pos = atomicAdd(&cnt[CRAG_CNT(q)], 1u);
+            if (pos < CRAG_CAND_CAP) out[pos] = k;
         }
     }
 }
@@ -733,27 +914,29 @@ int crag_launch_merge_rerank(const CragEntry* entries, int G, int B, int kc, int
     return (int)hipGetLastError();
 }
 
-int crag_launch_exact_keys(const QueryDesc* qd_host, const void* query, int dtype, int dim, int dim_pad, int metric,
-                           unsigned long long* keys, hipStream_t s) {
-    const long long n = qd_host->n_rows;
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_exact_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qd_host->rows, n, query,
-                       dtype, dim, dim_pad, metric, keys);
+int crag_launch_tau_refine(const FinalizeArgs& a, float* tau, unsigned int* cnt, uint32_t* segcnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_tau_refine, dim3(a.B), dim3(256), 0, s, a, tau, cnt, segcnt);
     return (int)hipGetLastError();
 }
 
-int crag_launch_hist64(const unsigned long long* keys, long long n, unsigned long long prefix,
-                       unsigned long long mask, int shift, unsigned int* hist256, hipStream_t s) {
-    long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_hist64, dim3((unsigned)blocks), dim3(256), 0, s, keys, n, prefix, mask, shift, hist256);
+int crag_launch_rescore_wide(const FinalizeArgs& a, unsigned long long* cand_rw, int n_failed, hipStream_t s) {
+    hipLaunchKernelGGL(k_rescore_wide, dim3(n_failed), dim3(1024), 0, s, a, cand_rw);
     return (int)hipGetLastError();
 }
 
-int crag_launch_gather_le(const unsigned long long* keys, long long n, unsigned long long thr,
-                          unsigned long long* out, unsigned int* out_cnt, unsigned int cap, hipStream_t s) {
-    long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_gather_le, dim3((unsigned)blocks), dim3(256), 0, s, keys, n, thr, out, out_cnt, cap);
+int crag_launch_exact_select(const ExactSelectArgs& a, hipStream_t s) {
+    if (a.F <= 0 || a.n_max <= 0) return 0;
+    const long long row_blocks = (a.n_max + 255) / 256;
+    if (row_blocks * a.F > 0x7fffffffll) return -2;
+    hipLaunchKernelGGL(k_exact_keys_b, dim3((unsigned)(row_blocks * a.F)), dim3(256), 0, s, a.qd, a.qmap, a.F, a.queries, a.dtype,
+                       a.dim, a.dim_pad, a.metric, a.keys, a.key_stride);
+    hipLaunchKernelGGL(k_radix_init, dim3(a.F), dim3(256), 0, s, a.qd, a.qmap, a.kc, a.state, a.hist, a.cnt);
+    long long blocks = row_blocks < 1024 ? row_blocks : 1024;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_hist64_b, dim3((unsigned)blocks, a.F), dim3(256), 0, s, a.keys, a.key_stride, a.qd, a.qmap, a.state, shift, a.hist);
+        hipLaunchKernelGGL(k_radix_pick, dim3(a.F), dim3(256), 0, s, a.state, shift, a.hist);
+    }
+    hipLaunchKernelGGL(k_gather_le_b, dim3((unsigned)blocks, a.F), dim3(256), 0, s, a.keys, a.key_stride, a.qd, a.qmap, a.state, a.cand,
+                       a.cand_stride, a.cnt);
     return (int)hipGetLastError();
 }

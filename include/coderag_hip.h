@@ -198,9 +198,11 @@ int crag_merge_rerank_device(int device, const void* entries_dev, int G, int B, 
                              int32_t* out_counts_dev, void* stream);
 
 /* ---- introspection (tests, bench) ------------------------------------------------------ */
-/* counters since the last reset: [0] searches, [1] queries, [2] exact-fallback queries,
- * [3] uncertified, [4] overflowed, [5] mfma-path batches, [6] gemv-path batches */
-int crag_stats(crag_index* h, int64_t* out7, int reset);
+/* counters since the last reset: [0] searches, [1] queries, [2] fallback queries (came back from the cascade without
+ * an exactness certificate), of which [3] uncertified and [4] overflowed, [5] mfma-path batches, [6] gemv-path
+ * batches, [7] fallback queries that needed the full exact scan, [8] fallback queries that went through the certified
+ * re-scan (the rest of [2] were settled by re-scoring their whole candidate buffer) */
+int crag_stats(crag_index* h, int64_t* out9, int reset);
 /* force a path for tests/bench: 0 auto, 1 gemv groups, 2 mfma */
 int crag_set_path(crag_index* h, int path);
 /*

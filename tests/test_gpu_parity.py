@@ -281,6 +281,81 @@ def test_mfma_massive_ties_overflow_segments_and_fall_back(coracle, nq):
     assert st["mfma_batches"] >= 1 and st["fallback"] >= 1
 
 
+@pytest.mark.parametrize("dtype,d,nq,path", [("bf16", 768, 40, "mfma"), ("f32", 384, 3, "gemv"), ("bf16", 1024, 20, "mfma"), ("f32", 384, 40, "mfma")])
+def test_duplicated_chunks_are_settled_by_rescoring_the_buffer(coracle, dtype, d, nq, path):
+    """Vendored copies and licence headers: a chunk that sits at a query's 2*top_k boundary exists 60 times, so the
+    slack of 16 re-scored rows cannot separate it and the certificate fails -- but the candidate buffer holds every
+    copy, so re-scoring the whole buffer exactly (fallback tier 1) settles the query without the full exact scan."""
+    n, top_k = 40000, 10
+    rows, queries, classes, rng = synth_case(n, d, dtype, nq, seed=83)
+    near = coracle.knn(rows, queries, 2 * top_k, "l2")[0]
+    for b in range(min(nq, 3)):                                   # the 15th nearest of the first queries, 60 copies each
+        src = int(near[b, 14])
+        where = rng.choice(np.arange(20000, n), size=60, replace=False)
+        rows[where] = rows[src]
+    col = make_collection(rows, dtype, "l2", None, classes)
+    col.set_path(path)
+    check_against_oracle(coracle, col, rows, queries, classes, None, top_k, 2.0, "l2", None)
+    st = col.stats()
+    assert st["fallback"] >= min(nq, 3) and st["exact_scan"] == 0, st
+
+
+@pytest.mark.parametrize("dtype,d,nq,path", [("f32", 384, 33, "auto"), ("bf16", 768, 140, "mfma"), ("f32", 384, 5, "gemv"),
+                                              ("bf16", 1024, 9, "mfma")])
+def test_whole_batch_of_massive_ties_is_settled_by_the_certified_rescan(coracle, dtype, d, nq, path):
+    """Every vector exists 3000 times and the queries are corpus vectors: each query's 2*top_k nearest are decided by
+    row id among 3000 exact ties and no certificate of the first pass can hold.  One more scan of the whole batch with
+    thresholds derived from the distances already known (fallback tier 1b) collects every tied row, and re-scoring
+    them exactly settles all queries -- no full exact scan."""
+    base = O.synth_unit_rows(160, d, 5, dtype)
+    rows = np.tile(base, (3000, 1))
+    queries = np.ascontiguousarray(base[:nq])
+    classes = (np.arange(len(rows)) % 3).astype(np.uint8)
+    col = make_collection(rows, dtype, "l2", None, classes)
+    col.set_path(path)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+    st = col.stats()
+    assert st["fallback"] == nq and st["rescan"] == nq and st["exact_scan"] == 0, st
+
+
+def test_whole_batch_through_the_exact_scan(coracle):
+    """More exact ties than a candidate buffer holds (three distinct vectors, 20000 copies each): every query of the
+    batch needs the full exact scan at once, and the batched device-side radix select must answer all of them."""
+    base = O.synth_unit_rows(3, 384, 5, "f32")
+    rows = np.tile(base, (20000, 1))
+    queries = np.concatenate([base, O.synth_unit_rows(30, 384, 6, "f32")])
+    classes = (np.arange(len(rows)) % 3).astype(np.uint8)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+    st = col.stats()
+    assert st["exact_scan"] == 33 and st["fallback"] == 33, st
+
+
+def test_fallback_inside_a_multi_collection_batch(coracle):
+    """search_multi where SOME collections force the exact scan (all-duplicate rows) and others do not: the failed
+    queries' own collections (different sizes) go through the batched fallback, the rest are untouched."""
+    d, top_k = 128, 5
+    cols, data = [], []
+    for i, (n, dup) in enumerate([(3000, False), (20000, True), (900, True), (12000, False), (7, True)]):
+        rows, _, classes, _ = synth_case(n, d, "f32", 1, seed=400 + i)
+        if dup:
+            rows[:] = rows[0]                                    # every row identical: ties decide everything
+        cols.append(make_collection(rows, "f32", "l2", None, classes, id_base=100_000 * i))
+        data.append((rows, classes))
+    order = [0, 1, 1, 2, 3, 4, 3]
+    q = O.synth_unit_rows(len(order), d, 998, "f32")
+    ids, sc, di, cn = ch.search_multi([cols[i] for i in order], q, top_k, 2.0)
+    for b, i in enumerate(order):
+        rows, classes = data[i]
+        (wi, ws, wd), = coracle.search_numeric(rows, q[b:b + 1], classes, None, top_k, 2.0, "l2", 100_000 * i)
+        k = len(wi)
+        assert int(cn[b]) == k and np.array_equal(ids[b, :k], wi) and np.array_equal(sc[b, :k], ws), (b, i)
+    st = cols[0].stats()                                          # counted on the first handle of the call
+    # 20000 identical rows overflow the candidate buffer (full exact scan, two queries); 900 identical rows fit their
+    # buffer whole, so re-scoring the buffer settles that query; 7 rows are all re-scored by the first pass already
+    assert st["fallback"] == 3 and st["exact_scan"] == 2, st
+
+
 def test_near_ties_force_the_exact_fallback(coracle):
     """Rows that differ from each other by one float32 ulp in one coordinate: the approximate scan
     cannot separate them, the certificate must fail and the exact fallback must still agree."""

@@ -249,7 +249,8 @@ def main():
     flops = 2.0 * B * scan_rows * d
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
-    traffic, traffic_src = pmc_traffic_checked(n, d, B) if top_k == 10 else (None, "committed passes are top-10 runs")
+    traffic, traffic_src = (pmc_traffic_checked(n, d, B) if top_k == (100 if B == 1024 else 10) else
+                            (None, "the committed passes are top-10 runs (top-100 at batch 1024)"))
     step_s = ms_per_step * 1e-3
     roofline = {
         "kernel": ("k_scan_qreg2" if B >= 2 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
@@ -400,12 +401,13 @@ def extra_regimes(col, q, n, d, torch):
         out.append({"regime": name, "queries_per_s": round(B * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 4),
                     "scan_kernel_ms": round(ms, 4), "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                     "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
-        pe = pmc_entry(n, d, B) if top_k == (100 if B == 1024 else 10) else {}
-        if pe.get("bytes"):
-            out[-1]["pmc_hbm_bytes_per_launch"] = pe["bytes"]  # rocprofv3 FETCH_SIZE pass, gfx950 correction applied
-            out[-1]["algorithmic_bytes_per_launch"] = int(sr * (d * 2 + 4))
-        if pe.get("mfma_busy_frac"):
-            out[-1]["pmc_mfma_busy_frac"] = pe["mfma_busy_frac"]  # matrix pipe busy cycles / (SIMDs x kernel cycles)
+        if top_k == (100 if B == 1024 else 10) and path == ("gemv" if B == 1 else "mfma"):
+            byts, _src = pmc_traffic_checked(n, d, B)   # None when the committed pass measured other kernel sources
+            if byts:
+                out[-1]["pmc_hbm_bytes_per_launch"] = byts  # rocprofv3 FETCH_SIZE pass, gfx950 correction applied
+                out[-1]["algorithmic_bytes_per_launch"] = int(sr * (d * 2 + 4))
+                if pmc_entry(n, d, B).get("mfma_busy_frac"):
+                    out[-1]["pmc_mfma_busy_frac"] = pmc_entry(n, d, B)["mfma_busy_frac"]  # matrix pipe busy cycles / (SIMDs x kernel cycles)
     col.set_path("auto")
     out.append(adversarial_regime(q, n, d, torch))
     return out

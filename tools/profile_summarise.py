@@ -1,17 +1,33 @@
-"""Filter the rocprofv3 output of tools/profile_regimes.sh (gpurun_out/<set>/) down to this library's kernels
-and write the summaries the docs cite into profiles/<set>_*:  python tools/profile_summarise.py r01k"""
+"""Filter the rocprofv3 output of tools/profile_regimes.sh (gpurun_out/<set>/) down to this library's kernels, write the
+summaries the docs cite into profiles/<set>_*, and refresh profiles/pmc_traffic.json (what bench.py reports as
+roofline.traffic while the kernel sources are the ones profiled):  python tools/profile_summarise.py r02a"""
 import collections
 import csv
+import glob
 import json
 import os
+import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01k"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02a"
 src = os.path.join("gpurun_out", tag)
+git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+sha = kernel_sources_sha()
 
 
 def ours(name):
     return "anonymous namespace)::k_" in name and "at::native" not in name
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pattern} under {src}")
+    return hits[0]
 
 
 def filt(inp, outp, key):
@@ -24,29 +40,48 @@ def filt(inp, outp, key):
     return keep
 
 
+def scan_counters(rows):
+    per = collections.defaultdict(dict)
+    for r in rows:
+        if "k_scan_" in r["Kernel_Name"]:
+            per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    return per
+
+
 summary = {}
-for name in ("b256", "b1", "b1024"):
-    st = filt(f"{src}/kt_{name}/{name}_kernel_stats.csv", f"profiles/{tag}_{name}_kernel_stats.csv", "Name")
-    tr = list(csv.DictReader(open(f"{src}/kt_{name}/{name}_kernel_trace.csv")))
-    pm = filt(f"{src}/pmc_{name}/{name}_counter_collection.csv", f"profiles/{tag}_{name}_pmc.csv", "Kernel_Name")
+traffic = {"_doc": "HBM-side bytes per launch of the dominant scan kernel (last cascade level) from rocprofv3 --pmc FETCH_SIZE, taken in a "
+                   "pass of its own on the same bench.py command, gfx950 correction applied: KiB x 1024 x 2 (MI355X_MICROARCH.md, HBM "
+                   "section). Key: rows|dim|batch. bench.py reports an entry as roofline.traffic only while kernel_sources_sha equals "
+                   "the sha of the sources it runs (bench.kernel_sources_sha)."}
+for name, B in (("b256", 256), ("b1", 1), ("b8", 8), ("b1024", 1024)):
+    st = filt(find(f"kt_{name}/**/{name}_kernel_stats.csv"), f"profiles/{tag}_{name}_kernel_stats.csv", "Name")
+    tr = list(csv.DictReader(open(find(f"kt_{name}/**/{name}_kernel_trace.csv"))))
+    pm = filt(find(f"pmc_{name}/**/{name}_counter_collection.csv"), f"profiles/{tag}_{name}_pmc.csv", "Kernel_Name")
     scans = [r for r in tr if "k_scan_" in r["Kernel_Name"]]
     dur = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in scans)
     longest = [d for d in dur if d > 0.5 * dur[-1]]  # the last cascade level of every step
-    per = collections.defaultdict(dict)
-    for r in pm:
-        if "k_scan_" in r["Kernel_Name"]:
-            per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
-    first = next(iter(per.values()))
-    key = "FETCH_SIZE" if "FETCH_SIZE" in first else "SQ_VALU_MFMA_BUSY_CYCLES"
-    best = max(per.values(), key=lambda c: c.get(key, 0))
-    s = {"last_level_launches": len(longest), "last_level_avg_ms": sum(longest) / len(longest) / 1e6, "counters_of_one_last_level_launch": best}
-    if key == "FETCH_SIZE":
-        s["hbm_bytes_per_launch"] = best["FETCH_SIZE"] * 1024 * 2  # KiB, and the gfx950 factor 2 (MI355X_MICROARCH.md)
-    else:
-        s["mfma_busy_frac"] = best["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * best["GRBM_GUI_ACTIVE"] / 8)
+    best = max(scan_counters(pm).values(), key=lambda c: c.get("FETCH_SIZE", 0))
+    kname = max(scans, key=lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))["Kernel_Name"]
+    s = {"kernel": kname, "last_level_launches": len(longest), "last_level_avg_ms": sum(longest) / len(longest) / 1e6,
+         "hbm_bytes_per_launch": best["FETCH_SIZE"] * 1024 * 2}  # KiB, and the gfx950 factor 2 (MI355X_MICROARCH.md)
+    entry = {"kernel": kname.split("::")[-1] + " (last cascade level)", "bytes": int(s["hbm_bytes_per_launch"]),
+             "fetch_size_kib": best["FETCH_SIZE"], "kernel_ms_kernel_trace": round(s["last_level_avg_ms"], 4),
+             "source": f"profiles/{tag}_{name}_pmc.csv, profiles/{tag}_{name}_kernel_stats.csv (tools/profile_regimes.sh, tools/profile_summarise.py)",
+             "kernel_sources_sha": sha, "git": git}
+    if name == "b1024":
+        pm2 = filt(find("pmc_b1024_mfma/**/b1024_counter_collection.csv"), f"profiles/{tag}_b1024_mfma_pmc.csv", "Kernel_Name")
+        b2 = max(scan_counters(pm2).values(), key=lambda c: c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0))
+        s["mfma_busy_frac"] = b2["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * b2["GRBM_GUI_ACTIVE"] / 8)
+        s["mfma_counters_of_one_last_level_launch"] = b2
+        entry.update({"mfma_busy_frac": round(s["mfma_busy_frac"], 4), "SQ_VALU_MFMA_BUSY_CYCLES": b2["SQ_VALU_MFMA_BUSY_CYCLES"],
+                      "SQ_INSTS_VALU_MFMA_MOPS_BF16": b2.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"), "GRBM_GUI_ACTIVE": b2["GRBM_GUI_ACTIVE"],
+                      "_how": "busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) for the last cascade level; "
+                              "MOPS x 512 = flop of that launch = 2 x 1024 x 768 x its rows; top-100 run"})
     summary[name] = s
+    traffic[f"10000000|768|{B}"] = entry
 with open(f"{src}/bench_full.log") as f:
     line = [l for l in f if l.startswith("{")][-1]
 open(f"profiles/{tag}_bench_full_line.json", "w").write(line)
 json.dump(summary, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -20,6 +20,7 @@ SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", 
            "crag_capi.hip"]
 INCLUDES = {"crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
             "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"], "crag_scan_qf32.hip": ["crag_qf32_kloop.inc"]}
+ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -90,10 +91,17 @@ def build(force=False, verbose=True):
         src = os.path.join(SRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or not _newer(obj, [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]):
+        deps = [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]
+        checked = s in ISA_CHECKED  # device ISA of the same sources and flags, for the fixed-register checks
+        asm = os.path.join(OBJ, s.replace(".hip", ".s"))
+        if force or not _newer(obj, deps):
             jobs.append(["hipcc"] + FLAGS + ["-c", src, "-o", obj])
-            if s in ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip"):  # device ISA of the same compilation, for the checks
-                jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", os.path.join(OBJ, s.replace(".hip", ".s"))])
+            if checked:
+                jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", asm])
+        elif checked and not _newer(asm, deps):
+            # the object is current but the listing that vouches for it is missing or older than a source: a check
+            # of a stale listing proves nothing about the object that ships
+            jobs.append(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", src, "-o", asm])
 
     def run(cmd):
         if verbose:
@@ -103,6 +111,11 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
+    for s in ISA_CHECKED:  # fail loudly rather than check a listing that does not belong to the object
+        src, asm, obj = os.path.join(SRC, s), os.path.join(OBJ, s.replace(".hip", ".s")), os.path.join(OBJ, s.replace(".hip", ".o"))
+        deps = [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]
+        if not os.path.exists(asm) or any(os.path.getmtime(d) > os.path.getmtime(asm) for d in deps):
+            raise RuntimeError(f"{asm} is missing or older than its sources: the fixed-register check would vouch for other code than {obj}")
     check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
     check_qsplit_isa(os.path.join(OBJ, "crag_scan_qsplit.s"))
     check_qf32_isa(os.path.join(OBJ, "crag_scan_qf32.s"))

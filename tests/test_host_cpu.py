@@ -258,3 +258,30 @@ def test_group_requests_one_launch_per_device_and_geometry():
     assert ch.group_requests([None, None]) == []
     flat = sorted(i for g in groups for i in g)
     assert flat == [0, 1, 3, 4, 5, 6, 7]                    # every live request exactly once
+
+
+# ---- the reference's mini eval metrics (eval/run_eval.py), /search half ----
+def test_eval_metrics_reproduce_the_committed_report():
+    """Hit@K / MRR@K / percentile as eval/run_eval.py computes them.  A ranking in which the three queries of
+    eval/qa_min.jsonl find their gold keys at ranks 1, 2 and 1 gives the reference's committed numbers
+    (eval/results/report.json: hit@5 1.0, mrr@5 0.8333...)."""
+    from coderag_hip import eval as E
+    qa = [{"id": "q1", "query": "What does asciiToArray do?", "expect": {"hit": ["lodash.js:asciiToArray"]}},
+          {"id": "q2", "query": "Find the implementation of lodash chunk", "expect": {"hit": ["lodash.js:chunk", "underscore.js:chunk"]}},
+          {"id": "q3", "query": "How to count unicode symbols length in lodash?", "expect": {"hit": ["lodash.js:stringSize", "lodash.js:hasUnicode"]}}]
+    answers = {"q1": [("lodash.js", "asciiToArray"), ("lodash.js", "x")],
+               "q2": [("lodash.js", "baseSlice"), ("underscore.js", "chunk"), ("lodash.js", "chunk")],
+               "q3": [("lodash.js", "hasUnicode"), ("lodash.js", "stringSize")]}
+    by_query = {x["query"]: x["id"] for x in qa}
+
+    def search_fn(query, top_k, sb):
+        assert (top_k, sb) == (5, 2.0)
+        return {"results": [{"path": p, "name": n} for p, n in answers[by_query[query]]]}
+
+    rep = E.evaluate_search(search_fn, qa, top_k=5)
+    assert rep["n"] == 3 and rep["search"]["hit@k"] == 1.0 and rep["search"]["mrr@k"] == (1 + 0.5 + 1) / 3
+    assert abs(rep["search"]["mrr@k"] - 0.8333333333333334) < 1e-15      # eval/results/report.json:6
+    assert E.mrr_at_k(["a:b"], ["x:y"]) == 0.0 and E.hit_at_k([], ["x:y"]) == 0.0
+    assert E.percentile([10.0, 20.0, 30.0, 40.0], 0.5) == 25.0 and E.percentile([], 0.95) == 0.0 and E.percentile([7.0], 0.95) == 7.0
+    boom = E.evaluate_search(lambda q, k, s: (_ for _ in ()).throw(RuntimeError("down")), qa[:1])
+    assert boom["search"]["hit@k"] == 0.0                                  # an error counts as no results

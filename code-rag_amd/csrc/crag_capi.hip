@@ -332,7 +332,8 @@ long long level1_rows(long long N, long long n0, int M, double direct_max) {
 // geometrically, n0 r^l, so every level is expected to add M r survivors; a level costs a launch and a
 // selection (~50 us), its survivors cost the filter's slow path on the tiles that hold them.  Same-box sweeps
 // (tools/sweep_tunables.sh history in DESIGN.md): at top-10 (M = 36) r between 3 and 6 is flat within 0.5 %, so
-// r ~ 6 (fewest launches); at top-100 (M = 225) r ~ 3 is 1.5-2 % ahead of r ~ 6 and of r ~ 2.
+// r ~ 6 (fewest launches), and up to r = 20 it stays within 0.5 % (round 2: a level saved is paid back by the
+// longer last level and its looser threshold); at top-100 (M = 225) r ~ 3 is 1.5-2 % ahead of r ~ 6 and of r ~ 2.
 constexpr int CRAG_MAX_LEVELS = 8;
 typedef SmallVec<long long, CRAG_MAX_LEVELS> LevelBounds;
 LevelBounds cascade_bounds(long long N, long long n0, int M) {

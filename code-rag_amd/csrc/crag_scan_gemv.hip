@@ -99,7 +99,10 @@ __device__ __forceinline__ float butterfly64(float (&v)[64], int lane) {
 // displacing what the L2 is for (queries, |x|^2, descriptors).  Same box, 10M rows, one query: 256 / 384 / 512 / 768
 // bf16 elements per row +9 / +12 / +9 / +12 % bandwidth (6.18 -> 6.92 TB/s at 768), but 1024 elements (2-KiB rows, 128-KiB
 // super-tiles: every wave's stream a power-of-two stride from its neighbours') -16 %, so rows of 128 chunks and more
-// keep the default policy.
+// keep the default policy.  (Tried for those rows with nt and dropped, same box: 8 / 12 / 16 / 24 waves per CU --
+// 3.98 / 5.29 / 4.03 / 5.29 TB/s, worst where the wave count is a power of two; 10 loads in flight instead of 6 --
+// no change; a start-time skew per wave -- no change; a contiguous block of super-tiles per wave instead of the
+// strided sweep -- slower at every row length, with and without nt.)
 #ifndef CRAG_GEMV_NT
 #define CRAG_GEMV_NT 1
 #endif

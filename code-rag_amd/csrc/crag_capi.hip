@@ -583,7 +583,8 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     float* tau = (float*)ws->tau.p;
     uint32_t* sample = (uint32_t*)ws->sample.p;
     unsigned long long* cand = nullptr;
-    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)B * CRAG_CNT_STRIDE + (size_t)B), st));
+    // no memset of the counters: level 0's selection (k_kth) writes every query's counter -- flat or per segment --
+    // when it seeds the buffers, and k_finalize writes every query's status
     const int n_seg = segmented ? crag_qreg2_segments(B, h0->n_cus) : 0;
     // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64): the COUNT must stay <= CAP
     const int seg_cap = segmented ? std::max(64, 2 * CRAG_CAND_CAP / n_seg) : 0;
@@ -606,7 +607,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         if ((rc = ws->segcnt.ensure(sizeof(uint32_t) * words))) return rc;
         segcnt = (uint32_t*)ws->segcnt.p;
         if (paced) progress = segcnt + seg_words;
-        HIPCHK(hipMemsetAsync(segcnt, 0, sizeof(uint32_t) * words, st));
+        if (paced) HIPCHK(hipMemsetAsync(progress, 0, sizeof(uint32_t) * prog_words * CRAG_MAX_LEVELS, st));  // pacing words start at zero
     }
 
     // ---- passes ----

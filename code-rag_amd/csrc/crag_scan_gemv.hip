@@ -28,12 +28,19 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 // v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.   v_permlane16_swap: odd 16-lane rows
 // of a <-> even rows of b.  Inline asm, because hipcc (ROCm 7.2) folds the builtin's second
 // result onto the first (__builtin_amdgcn_permlane32_swap(...)[1] reads vdst, seen on hardware).
-// The two leading wait states cover the VALU-write -> permlane-read hazard inside the string.
+// The leading wait states are this code's job -- the compiler inserts no hazard nops inside an asm statement:
+//   * a VALU write followed by a permlane swap that reads the register needs 2 wait states;
+//   * the first stage's inputs are accumulators that v_dot2c_f32_bf16 wrote, and on gfx940+ a DOT result needs
+//     3 wait states before a different VALU instruction reads it and 4 before one overwrites it (the swap does
+//     both).  hipcc schedules each swap right behind the last dot of its two accumulators; with only two wait
+//     states the LAST pair (rows 31 and 63 of a super-tile) read a stale accumulator whenever nothing else sat
+//     in between -- found by tools/fuzz_more.py on 1536-element bf16 rows, one query (round 2; the bug was in
+//     round 1's kernel too, where no test reached that variant).  s_nop 4 = five wait states covers all three.
 __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 4\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 4\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 template <int DT>
@@ -96,25 +103,26 @@ __device__ __forceinline__ float butterfly64(float (&v)[64], int lane) {
 }
 
 // Corpus rows are read once per pass by one wave: nontemporal loads (global_load_dwordx4 ... nt) keep them from
-// displacing what the L2 is for (queries, |x|^2, descriptors).  Same box, 10M rows, one query: 256 / 384 / 512 / 768
-// bf16 elements per row +9 / +12 / +9 / +12 % bandwidth (6.18 -> 6.92 TB/s at 768), but 1024 elements (2-KiB rows, 128-KiB
-// super-tiles: every wave's stream a power-of-two stride from its neighbours') -16 %, so rows of 128 chunks and more
-// keep the default policy.  (Tried for those rows with nt and dropped, same box: 8 / 12 / 16 / 24 waves per CU --
-// 3.98 / 5.29 / 4.03 / 5.29 TB/s, worst where the wave count is a power of two; 10 loads in flight instead of 6 --
-// no change; a start-time skew per wave -- no change; a contiguous block of super-tiles per wave instead of the
-// strided sweep -- slower at every row length, with and without nt.)
+// displacing what the L2 is for (queries, |x|^2, descriptors).  Same box, one query, 6-10M rows: 256 / 384 / 512 / 768
+// bf16 elements per row +9 / +12 / +9 / +12 % bandwidth (6.18 -> 6.92 TB/s at 768), 1024 / 1536 / 2048 elements
+// +12 % each (6.0-6.2 -> 6.8-6.95 TB/s).  An earlier measurement had the long rows LOSE 16 % with nt; that was
+// taken on a kernel whose loads the compiler had serialised (see the fence in the dot loop and the xnorm pointer),
+// and so were the experiments made on it (waves per CU, loads in flight, start skew, blocked assignment).
+// Also measured and dropped after the fix: a two-waves-per-SIMD occupancy hint for the 192/256-chunk variants
+// (256 VGPRs instead of 264-270: -1 %).
 #ifndef CRAG_GEMV_NT
 #define CRAG_GEMV_NT 1
 #endif
 template <bool NT>
 __device__ __forceinline__ uint4 load_row_chunk(const uint4* p) {
-    if constexpr (NT) {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-        const u32x4_t v = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4_t*)p);  // global, not flat
-        return make_uint4(v.x, v.y, v.z, v.w);
-    } else {
-        return *p;
-    }
+    // explicitly GLOBAL: in the long-row variants hipcc otherwise falls back to flat loads, which also count in
+    // lgkmcnt and were waited for one at a time
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const __attribute__((address_space(1))) u32x4_t* g = (const __attribute__((address_space(1))) u32x4_t*)p;
+    u32x4_t v;
+    if constexpr (NT) v = __builtin_nontemporal_load(g);
+    else v = *g;
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 template <int DT, int C, int NQ>
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     constexpr int RT = 64 / NQ;               // rows per super-tile
     constexpr int NL = RT * C / 64;           // wave loads per super-tile
     constexpr int U = NL < 6 ? NL : 6;        // loads in flight per wave
-    constexpr bool NT = CRAG_GEMV_NT && C < 128;
+    constexpr bool NT = CRAG_GEMV_NT;
     static_assert(RT % PR == 0, "super-tile must hold whole periods");
     static_assert(C >= 32, "a wave load may span at most two rows");
 
@@ -150,7 +158,11 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
     const int w = (bid - gp->blk_first[pass]) * 4 + wave;
     const int nq = gp->nq;  // real queries in this group (<= NQ); the rest are padding
     const int q_first = gp->q_first;
-    const float* __restrict__ xnorm = gp->xnorm;
+    // pointers read from the descriptor are generic to the compiler; a FLAT load of xnorm would stay "pending" for
+    // the wait-count pass until the norm is used after the dot loop, and every wait inside the loop then becomes
+    // vmcnt(0) (drain all loads in flight) instead of vmcnt(U-1).  Global address space keeps the count exact.
+    const __attribute__((address_space(1))) float* __restrict__ xnorm =
+        (const __attribute__((address_space(1))) float*)gp->xnorm;
 
     // per-lane query chunks: the lane's chunk-in-row repeats with period PL loads
     uint4 qreg[PL][NQ];
@@ -197,6 +209,10 @@ __global__ __launch_bounds__(256) void k_scan_gemv(const GroupDesc* __restrict__
                 const int rel = 64 * (n + U) + lane;
                 buf[n % U] = load_row_chunk<NT>(base + (rel < rel_max ? rel : rel_max));
             }
+            // the load above stays ABOVE this chunk's dots: without the fence hipcc's scheduler sinks each load
+            // next to its use in some variants (128/192/256 chunks per row, one query) and the wave then waits
+            // for one load at a time
+            __builtin_amdgcn_sched_barrier(0);
             const int row_lo = (64 * n) / C;
             const int row_hi = (64 * n + 63) / C;
             if (row_lo == row_hi) {

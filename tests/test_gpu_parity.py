@@ -222,6 +222,49 @@ def test_scan_error_bound(dtype, d, nq, path):
     assert err.max() < 2e-6          # typical error is ~1e-7: the bound has three orders of margin
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_gemv_every_compiled_variant(dtype):
+    """Every k_scan_gemv<DT, C, NQ> the library compiles (C = 16-byte chunks per row: 32..256, NQ = queries per
+    lane group: 1, 2, 4, 8), each scored on every (query, row) pair against fp64.  The variants are separate
+    instruction schedules: round 2's fuzz found <bf16, 192, 1> and <bf16, 256, 1> reading an accumulator too soon
+    after its last v_dot2c (wrong score for the last row of a 64-row tile) while every other variant was right."""
+    import torch
+    per16 = 8 if dtype == "bf16" else 4
+    worst = 0.0
+    for chunks in (32, 48, 64, 96, 128, 192, 256):
+        d = chunks * per16
+        if dtype == "f32" and d > 1024:
+            continue
+        for d_use in (d, d - 3 * per16 - 1):       # the padded tail of a row too
+            rows = O.synth_unit_rows(1500, d_use, chunks, dtype)
+            qs = O.synth_unit_rows(8, d_use, chunks + 1, dtype)
+            col = make_collection(rows, dtype)
+            assert col.dim_pad * (2 if dtype == "bf16" else 4) // 16 == chunks
+            X, Q = O.as_f64(rows), O.as_f64(qs)
+            ref = (X * X).sum(1)[None, :] - 2.0 * Q @ X.T
+            for nq in (1, 2, 3, 8):
+                q = torch.from_numpy(qs[:nq]).cuda() if dtype == "f32" else \
+                    torch.from_numpy(qs[:nq].view(np.int16)).cuda().view(torch.bfloat16)
+                for rep in range(2):
+                    got = col.debug_dense_scores(q, "gemv").cpu().numpy().astype(np.float64)
+                    err = np.abs(got - ref[:nq])
+                    bad = np.argwhere(err > 2e-6)
+                    assert len(bad) == 0, (dtype, chunks, d_use, nq, float(err.max()), bad[:6].tolist())
+                    worst = max(worst, float(err.max()))
+            col.close()
+    assert worst < 2e-6
+
+
+@pytest.mark.parametrize("d,n,nq", [(1536, 30011, 1), (2048, 9000, 1), (1536, 9000, 2), (1100, 9000, 1)])
+def test_parity_long_bf16_rows_few_queries(coracle, d, n, nq):
+    """Rows longer than 1024 elements with one or two queries: the 192- and 256-chunk GEMV variants end to end."""
+    rows, queries, classes, _ = synth_case(n, d, "bf16", nq, seed=d + nq)
+    col = make_collection(rows, "bf16", "l2", None, classes)
+    for top_k in (10, 200):
+        check_against_oracle(coracle, col, rows, queries, classes, None, top_k, 2.0, "l2", None)
+    assert col.stats()["fallback"] == 0
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 19, 20, 21, 63, 64, 65, 127, 129, 4095, 4097])
 def test_small_and_ragged_collections(coracle, n):
     rows, queries, classes, _ = synth_case(n, 384, "f32", 2, seed=5)

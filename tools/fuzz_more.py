@@ -1,0 +1,140 @@
+"""Extended seeded fuzz against the C oracle (not part of the test suite; run on the GPU box):
+random shapes through the auto dispatch with injected duplicates / near-duplicates (so that every fallback tier is
+hit), single-collection batches and multi-collection batches, host-buffer and device-buffer entry points.
+
+    python tools/fuzz_more.py [cases] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "code-rag_amd")):
+    sys.path.insert(0, p)
+import numpy as np
+import coderag_hip as ch
+from oracle import coracle, oracle as O
+
+coracle.build()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+tot = {"fallback": 0, "rescan": 0, "exact_scan": 0}
+t0 = time.time()
+ONLY = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None  # replay one case (the draws of the others are consumed)
+
+
+def make_rows(n, d, dtype, dup_mode, seed):
+    rows = O.synth_unit_rows(n, d, seed, "f32")
+    r = np.random.default_rng(seed + 7)
+    if dup_mode == 1 and n > 50:            # a few vectors with many copies
+        for _ in range(3):
+            src = int(r.integers(0, n))
+            where = r.choice(n, size=min(n // 3, int(r.choice([30, 200, 3000]))), replace=False)
+            rows[where] = rows[src]
+    elif dup_mode == 2 and n > 50:          # near-duplicates: one ulp apart in one coordinate
+        src = int(r.integers(0, n))
+        where = r.choice(n, size=min(n // 2, 400), replace=False)
+        rows[where] = rows[src]
+        for w in where:
+            c = int(r.integers(0, d))
+            rows[w, c] = np.nextafter(rows[w, c], np.float32(np.inf if w % 2 else -np.inf))
+    elif dup_mode == 3:                     # everything identical
+        rows[:] = rows[0]
+    if dtype == "bf16":
+        rows = O.f32_to_bf16_bits(rows)
+    return rows
+
+
+def check(got, want, tag):
+    ids, sc, di, cn = got
+    for b, (wi, ws, wd) in enumerate(want):
+        k = len(wi)
+        ok = int(cn[b]) == k and np.array_equal(ids[b, :k], wi) and np.array_equal(sc[b, :k], ws) and \
+            np.array_equal(di[b, :k].view(np.uint32), wd.view(np.uint32))
+        if not ok:
+            print("MISMATCH", tag, "query", b, "count", int(cn[b]), "want", k, flush=True)
+            kk = min(k, int(cn[b]))
+            bad = [j for j in range(kk) if ids[b, j] != wi[j] or sc[b, j] != ws[j] or di[b, j].view(np.uint32) != wd[j].view(np.uint32)]
+            print("first differing ranks", bad[:10], flush=True)
+            for j in bad[:5]:
+                print(j, "got", ids[b, j], sc[b, j], di[b, j], "want", wi[j], ws[j], wd[j], flush=True)
+            sys.exit(1)
+
+
+for case in range(n_cases):
+    dtype = "bf16" if rng.random() < 0.6 else "f32"
+    d = int(rng.choice([64, 100, 128, 256, 384, 512, 768, 1000, 1024, 1536]))
+    if dtype == "f32" and d > 1024:
+        d = 1024
+    top_k = int(rng.choice([1, 5, 10, 10, 37, 100, 200]))
+    metric = "l2" if rng.random() < 0.75 else "ip"
+    multi = rng.random() < 0.3
+    seed = 10_000 + case
+    if not multi:
+        n = int(rng.choice([40, 1000, 8193, 20000, 40000]))
+        nq = int(rng.choice([1, 2, 3, 9, 33, 64, 130, 257]))
+        while n * nq * d > 1.2e9:
+            n //= 2
+        dup = int(rng.choice([0, 1, 1, 2, 3])) if metric == "l2" or rng.random() < 0.5 else 0
+        skip = ONLY is not None and case != ONLY
+        classes = rng.integers(0, 3, size=n).astype(np.uint8)
+        pick = rng.integers(0, n, size=max(1, nq // 2)) if (dup and nq > 1) else None
+        if skip:
+            continue
+        rows = make_rows(n, d, dtype, dup, seed)
+        queries = O.synth_unit_rows(nq, d, seed + 1, "f32")
+        if dup and nq > 1:
+            src = O.bf16_bits_to_f32(rows[pick]) if dtype == "bf16" else rows[pick]
+            queries[:len(pick)] = src
+        if dtype == "bf16":
+            queries = O.f32_to_bf16_bits(queries)
+        col = ch.GpuCollection(d, dtype, metric)
+        col.add(rows, path_class=classes)
+        col.finalize()
+        qf = O.bf16_bits_to_f32(queries) if dtype == "bf16" else queries
+        want = coracle.search_numeric(rows, queries, classes, None, top_k, 2.0, metric)
+        check(col.search(qf, top_k, 2.0), want, (case, dtype, d, n, nq, top_k, metric, dup))
+        st = col.stats()
+        for k in tot:
+            tot[k] += st[k]
+        col.close()
+    else:
+        ncol = int(rng.integers(2, 7))
+        cols, data = [], []
+        skip = ONLY is not None and case != ONLY
+        for c in range(ncol):
+            n = int(rng.choice([5, 300, 5000, 9000, 30000]))
+            dup = int(rng.choice([0, 0, 1, 3]))
+            classes = rng.integers(0, 3, size=n).astype(np.uint8)
+            if skip:
+                continue
+            rows = make_rows(n, d, dtype, dup, seed + 100 * c)
+            if ONLY is not None:
+                print("collection", c, "rows", n, "dup", dup, flush=True)
+            col = ch.GpuCollection(d, dtype, metric)
+            col.add(rows, path_class=classes)
+            col.set_id_base(1_000_000 * c)
+            col.finalize()
+            cols.append(col)
+            data.append((rows, classes))
+        order = sorted(int(x) for x in rng.integers(0, ncol, size=int(rng.choice([2, 5, 17, 40]))))
+        if skip:
+            continue
+        queries = O.synth_unit_rows(len(order), d, seed + 1, "f32")
+        if dtype == "bf16":
+            queries = O.f32_to_bf16_bits(queries)
+        qf = O.bf16_bits_to_f32(queries) if dtype == "bf16" else queries
+        got = ch.search_multi([cols[i] for i in order], qf, top_k, 2.0)
+        want = []
+        for b, i in enumerate(order):
+            rows, classes = data[i]
+            want += coracle.search_numeric(rows, queries[b:b + 1], classes, None, top_k, 2.0, metric, 1_000_000 * i)
+        check(got, want, (case, "multi", dtype, d, order, top_k, metric))
+        st = cols[order[0]].stats()
+        for k in tot:
+            tot[k] += st[k]
+        for c in cols:
+            c.close()
+    if case % 20 == 19:
+        print(f"{case + 1} cases ok, {time.time() - t0:.0f} s, fallbacks so far {tot}", flush=True)
+print("ALL OK", n_cases, tot, flush=True)

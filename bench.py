@@ -48,6 +48,18 @@ def pmc_traffic(n, d, B):
     return pmc_entry(n, d, B).get("bytes")
 
 
+def scan_kernel_name(d, B, path):
+    """The scan the library's auto dispatch takes for bf16 rows of d elements and B queries of one collection
+    (crag_capi.hip: search_entries_chunk_launch)."""
+    if path == "gemv":
+        return "k_scan_gemv"
+    if d > 1024:
+        return "k_scan_qlong" if (B >= 9 or path == "mfma") else "k_scan_gemv"
+    if d > 768:
+        return "k_scan_qsplit"
+    return "k_scan_qreg2" if (B >= (2 if d >= 768 else 3) or path == "mfma") else "k_scan_gemv"
+
+
 def kernel_sources_sha():
     """sha256 over the scan/select kernel sources the PMC passes were taken on (profiles/pmc_traffic.json records
     it per entry): a committed traffic figure is only reported while the kernels it measured are the ones built."""
@@ -253,7 +265,7 @@ def main():
                             (None, "the committed passes are top-10 runs (top-100 at batch 1024)"))
     step_s = ms_per_step * 1e-3
     roofline = {
-        "kernel": ("k_scan_qreg2" if B >= 2 else "k_scan_gemv") + " (last cascade level: every row behind the earlier levels)",
+        "kernel": scan_kernel_name(d, B, args.path) + " (last cascade level: every row behind the earlier levels)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,

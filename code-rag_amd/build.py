@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip", "crag_select.hip",
-           "crag_capi.hip"]
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip", "crag_scan_qlong.hip",
+           "crag_select.hip", "crag_capi.hip"]
 INCLUDES = {"crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
             "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"], "crag_scan_qf32.hip": ["crag_qf32_kloop.inc"]}
 ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip")

@@ -1,0 +1,217 @@
+// Batched scan for bf16 rows LONGER than 1024 elements (dim_pad 1536 / 2048), gfx950.
+//
+// Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
+// /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection, for the row
+// lengths whose queries do not fit a wave's registers (96 / 128 MFMA fragments per 32 queries = 384 / 512
+// registers before the first accumulator): the query-stationary scans (crag_scan_qreg2 / qsplit) stop at 1024
+// elements, and without this kernel such rows are scanned by GEMV groups of 8 queries, i.e. the corpus is read
+// B / 8 times (tools/sweep_auto.py, round 2: 256 queries on 1.3M x 1536 took 16 ms, 15x the 768-element case).
+//
+// Neither operand is stationary: a workgroup owns a tile of 128 corpus rows x 128 queries and walks K in steps of
+// 64 elements; both operands go HBM/L2 -> registers -> LDS (two stages, one barrier per step) and from there
+// as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16.  Corpus rows are the A operand and queries the B operand,
+// so the accumulator puts the QUERY on the lane (column = lane & 31) and 16 rows in the lane's registers: tau is
+// one VGPR per lane and the fused filter is 16 compares per accumulator, as in the query-stationary scans.
+// 128-byte LDS rows, XOR swizzle slot = chunk ^ ((row >> 1) & 7): the fragment reads are conflict-free.
+// Workgroups that share a row tile (B > 128: one per 128 queries) are eight apart in the grid, so they run on the
+// same XCD and the second one finds the tile in that XCD's L2.
+//
+// Same contract as the one-block query-stationary scans (MfmaArgs in crag_common.h):
+//   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced over queries)
+//   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's flat candidate buffer
+#include "crag_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+constexpr int QL_TM = 128;  // corpus rows per tile
+constexpr int QL_TN = 128;  // queries per tile
+constexpr int QL_BK = 64;   // k elements per stage (128 bytes per row)
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <bool NT>
+__device__ __forceinline__ uint4 load16(const uint4* p) {
+    const __attribute__((address_space(1))) u32x4_t* g = (const __attribute__((address_space(1))) u32x4_t*)p;
+    u32x4_t v;
+    if constexpr (NT) v = __builtin_nontemporal_load(g);
+    else v = *g;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned short* __restrict__ rows,
+                                                       const float* __restrict__ xnorm, long long row_begin,
+                                                       long long row_end, const unsigned short* __restrict__ queries,
+                                                       int n_queries, int n_qtiles, int dim_pad, int metric,
+                                                       const float* __restrict__ tau, uint32_t* __restrict__ sample,
+                                                       long long sample_stride, unsigned long long* __restrict__ cand,
+                                                       uint32_t* __restrict__ cnt) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][QL_TM * 128];  // [stage][A|B][16 KiB]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // grid index -> (row tile, query tile): the query tiles of one row tile are 8 blocks apart (same XCD)
+    const long long bid = blockIdx.x;
+    const long long per = 8LL * n_qtiles;
+    const long long grp = bid / per;
+    const int rem = (int)(bid - grp * per);
+    const int qt = rem >> 3;
+    const long long rt = grp * 8 + (rem & 7);
+    const long long row0 = row_begin + rt * QL_TM;
+    if (row0 >= row_end) return;  // the last group of eight row tiles may be ragged (uniform per workgroup)
+    const int q0 = qt * QL_TN;
+
+    // staging geometry: thread handles chunks id = tid + 256*i (i<4): row = id>>3, chunk = id&7
+    const uint4* gA[4];
+    const uint4* gB[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        const int r = id >> 3, c = id & 7;
+        long long ar = row0 + r;
+        if (ar >= row_end) ar = row_end - 1;
+        int qr = q0 + r;
+        if (qr >= n_queries) qr = n_queries - 1;
+        gA[i] = (const uint4*)(rows + ar * dim_pad) + c;
+        gB[i] = (const uint4*)(queries + (long long)qr * dim_pad) + c;
+        soff[i] = lds_off(r, c);
+    }
+    const int KT = dim_pad / QL_BK;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = load16<NT>(gA[i]);
+        rb[i] = load16<false>(gB[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *(uint4*)(&lds[0][0][soff[i]]) = ra[i];
+        *(uint4*)(&lds[0][1][soff[i]]) = rb[i];
+    }
+    __syncthreads();
+
+    // fragment read offsets (per k-step s the chunk is 2s + (lane>>5))
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = load16<NT>(gA[i] + (kt + 1) * 8);
+                rb[i] = load16<false>(gB[i] + (kt + 1) * 8);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wr * 64 + i * 32 + fr;
+                a[i] = *(const bf16x8_t*)(&lds[cur][0][lds_off(r, 2 * s + fh)]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wc * 64 + j * 32 + fr;
+                b[j] = *(const bf16x8_t*)(&lds[cur][1][lds_off(r, 2 * s + fh)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(uint4*)(&lds[cur ^ 1][0][soff[i]]) = ra[i];
+                *(uint4*)(&lds[cur ^ 1][1][soff[i]]) = rb[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // fused epilogue: query on the lane, 16 corpus rows per accumulator
+    const float c2 = metric == CRAG_L2 ? -2.f : -1.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + wc * 64 + j * 32 + fr;
+        const bool qok = q < n_queries;
+        const float tq = (MODE == 1 && qok) ? tau[q] : -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long mb = row0 + wr * 64 + i * 32 + 4 * fh;
+            float sc[16];
+            bool hit = false;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (metric == CRAG_L2) xn = *(const float4*)(xnorm + mb + 8 * g4);  // xnorm is padded by 256 floats
+                const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sc[g4 * 4 + e] = fmaf(c2, acc[i][j][g4 * 4 + e], xv[e]);
+                    hit = hit || sc[g4 * 4 + e] <= tq;
+                }
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = mb + 8 * (r >> 2) + (r & 3);
+                    if (qok && m < row_end) sample[m * sample_stride + q] = crag_fkey(sc[r]);
+                }
+            } else if (__any(hit)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = mb + 8 * (r >> 2) + (r & 3);
+                    if (sc[r] <= tq && m < row_end) {
+                        const unsigned pos = atomicAdd(&cnt[CRAG_CNT(q)], 1u);
+                        if (pos < CRAG_CAND_CAP)
+                            cand[(long long)q * CRAG_CAND_CAP + pos] =
+                                ((unsigned long long)crag_fkey(sc[r]) << 32) | (unsigned long long)(uint32_t)m;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, bool NT>
+int launch_one(const MfmaArgs& a, long long blocks, int qtiles, hipStream_t s) {
+    hipLaunchKernelGGL((k_scan_qlong<MODE, NT>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)a.rows,
+                       a.xnorm, a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, qtiles, a.dim_pad,
+                       a.metric, a.tau, a.sample, a.sample_stride, a.cand, a.cnt);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool crag_qlong_supported(int dim_pad) { return dim_pad > 1024 && dim_pad <= 2048 && dim_pad % QL_BK == 0; }
+
+// sample layout of this kernel: sample[row * sample_stride + query]  (row-major)
+int crag_launch_scan_qlong(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
+    (void)n_cus;
+    if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
+    if (a.row_begin % 32 || !crag_qlong_supported(a.dim_pad)) return -1;
+    const long long rtiles = (a.row_end - a.row_begin + QL_TM - 1) / QL_TM;
+    const int qtiles = (a.n_queries + QL_TN - 1) / QL_TN;
+    const long long blocks = (rtiles + 7) / 8 * 8 * qtiles;
+    if (blocks > 0x7fffffffLL) return -1;
+    const bool nt = qtiles == 1;  // a row tile read by one workgroup only: keep it out of the L2
+    if (mode == 0) return nt ? launch_one<0, true>(a, blocks, qtiles, s) : launch_one<0, false>(a, blocks, qtiles, s);
+    return nt ? launch_one<1, true>(a, blocks, qtiles, s) : launch_one<1, false>(a, blocks, qtiles, s);
+}

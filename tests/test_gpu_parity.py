@@ -159,11 +159,20 @@ def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     assert st["mfma_batches"] >= 1
 
 
-@pytest.mark.parametrize("d,n,nq,top_k,metric", [(1536, 3000, 9, 10, "l2"), (2048, 2500, 130, 100, "l2"), (1100, 3000, 33, 10, "ip"),
-                                                 (2048, 9000, 2, 10, "ip")])
-def test_parity_long_bf16_rows_stay_on_gemv_groups(coracle, d, n, nq, top_k, metric):
-    """bf16 rows longer than 1024 elements have no query-stationary MFMA scan: the auto path serves them with GEMV
-    groups of 8 queries at every batch size (the 128x128 LDS-tiled MFMA kernel that used to take them is gone)."""
+@pytest.mark.parametrize("d,n,nq,top_k,metric,scan", [
+    (1536, 3000, 8, 10, "l2", "gemv"),          # below the switch-over (9 queries): one GEMV group of 8
+    (2048, 9000, 2, 10, "ip", "gemv"),
+    (2048, 2500, 130, 100, "l2", "mfma"),       # two query tiles of 128, ragged second one; one ragged row tile
+    (1100, 3000, 33, 10, "ip", "mfma"),         # padded to 1536
+    (1536, 30011, 9, 10, "l2", "mfma"),         # the first batch size that takes it; several cascade levels
+    (1536, 20000, 300, 100, "l2", "mfma"),      # three query tiles: workgroups that share a row tile, default loads
+    (2048, 127, 40, 10, "l2", "mfma"),          # less than one row tile
+    (1536, 129, 64, 200, "ip", "mfma"),         # one row past a tile; top-200 of 129 rows
+])
+def test_parity_long_bf16_rows(coracle, d, n, nq, top_k, metric, scan):
+    """bf16 rows longer than 1024 elements have no query-stationary MFMA scan (the queries do not fit a wave's
+    registers): the auto path serves small batches with one GEMV group of up to 8 queries and batches of 9 and more with the
+    LDS-tiled scan of crag_scan_qlong.hip (128 rows x 128 queries per workgroup)."""
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=79)
     match = np.zeros((nq, n), np.uint8)
     match[:2] = rng.random((2, n)) < 0.08
@@ -172,7 +181,30 @@ def test_parity_long_bf16_rows_stay_on_gemv_groups(coracle, d, n, nq, top_k, met
     col = make_collection(rows, "bf16", metric, names, classes)
     check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, metric, texts)
     st = col.stats()
-    assert st["gemv_batches"] >= 1 and st["mfma_batches"] == 0
+    if scan == "gemv":
+        assert st["gemv_batches"] >= 1 and st["mfma_batches"] == 0
+    else:
+        assert st["mfma_batches"] >= 1 and st["gemv_batches"] == 0
+    assert st["fallback"] == 0
+
+
+def test_long_bf16_rows_duplicates_take_the_fallback_tiers(coracle):
+    """Every fallback tier behind the LDS-tiled long-row scan: duplicated vectors at the 2*top_k boundary (tier 1),
+    a certified re-scan (tier 1b goes through the same kernel with its refined tau), and a collection of identical rows."""
+    n, d, nq = 6000, 1536, 24
+    rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=81)
+    rows[100:400] = rows[7]
+    rows[2000:2400] = rows[1999]
+    queries[:4] = rows[7]
+    queries[4:8] = rows[1999]
+    col = make_collection(rows, "bf16", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+    st = col.stats()
+    assert st["mfma_batches"] >= 1 and st["fallback"] >= 8
+    rows[:] = rows[0]
+    col2 = make_collection(rows, "bf16", "l2", None, classes)
+    check_against_oracle(coracle, col2, rows, queries, classes, None, 10, 2.0, "l2", None)
+    assert col2.stats()["fallback"] == nq
 
 
 @pytest.mark.parametrize("d,n,nq,top_k,metric", [
@@ -200,7 +232,8 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               ("f32", 256, 129, "mfma"), ("f32", 384, 3, "gemv"), ("bf16", 768, 8, "gemv"), ("bf16", 768, 40, "mfma"),
                                               ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma"),
                                               ("bf16", 768, 150, "mfma"), ("bf16", 384, 129, "mfma"), ("bf16", 512, 256, "mfma"),
-                                              ("bf16", 256, 192, "mfma"), ("bf16", 1000, 140, "mfma"), ("bf16", 1024, 9, "mfma")])
+                                              ("bf16", 256, 192, "mfma"), ("bf16", 1000, 140, "mfma"), ("bf16", 1024, 9, "mfma"),
+                                              ("bf16", 1536, 40, "mfma"), ("bf16", 2048, 130, "mfma"), ("bf16", 1500, 3, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

@@ -422,6 +422,7 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
 // launch, candidate-buffer memory), so larger batches run as consecutive chunks on the same stream.
 constexpr int CRAG_MAX_CHUNK = 2048;
 // bf16 rows longer than 1024 elements: batches from this size up take crag_scan_qlong.hip instead of GEMV groups
+constexpr int CRAG_QLONG_FROM_F32 = 25;  // float32 MFMA is 16x slower than bf16: four GEMV groups (2.4 ms on 4 GB) against one pass (2.25 ms)
 constexpr int CRAG_QLONG_FROM = 9;  // two GEMV groups (3M x 1536: 2.8 ms) against one pass of this scan (1.8 ms)
 int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                    const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
@@ -482,16 +483,16 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     const bool bf16 = h0->dtype == CRAG_BF16;
     const bool can_qreg = bf16 && crag_qreg2_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
     const bool can_qf32 = !bf16 && crag_qf32_supported(h0->dim_pad);
-    const bool can_qlong = bf16 && crag_qlong_supported(h0->dim_pad);
+    const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad);
     // float32: the MFMA form (up to 128 queries per pass, MFMA-bound at 1.8 TB/s-equivalent) overtakes the GEMV
     // (8 queries per group at ~4.5 TB/s, groups partly overlapping) where the GEMV needs a fourth group
     // (tools/sweep_small_batch.py 384 f32: B = 16 2.45 vs 3.40 ms, B = 32 4.66 vs 3.44 ms on 4M rows).
     // bf16 rows longer than 1024 elements have no query-stationary form; from CRAG_QLONG_FROM queries up they take the
-    // LDS-tiled scan (crag_scan_qlong.hip: corpus read once per 128 queries instead of once per 8).  float32 rows
-    // longer than 384 elements stay on the GEMV groups at every batch size.
+    // LDS-tiled scan (crag_scan_qlong.hip: corpus read once per 128 queries instead of once per 8); so do float32
+    // rows longer than 384 elements from CRAG_QLONG_FROM_F32 queries up.
     // 1024-element rows: the split-K scan with nontemporal DMA is ahead of the GEMV even for ONE query (same box,
     // 1M / 3M / 10M rows: 0.42 vs 0.46, 1.00 vs 1.13, 2.99 vs 3.42 ms); at 768 elements one query is a tie
-    const int mfma_from = can_qlong ? CRAG_QLONG_FROM : can_qf32 ? 25 : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
+    const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : CRAG_QLONG_FROM_F32) : can_qf32 ? 25 : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
     P.mfma = same_handle && (can_qreg || can_qsplit || can_qf32 || can_qlong) && (path == 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
@@ -664,7 +665,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         auto launch_level = [&](int mode) -> int {
             if (segmented) return crag_launch_scan_qreg2(ma, mode, h0->n_cus, st);
             if (qsplit) return crag_launch_scan_qsplit(ma, mode, h0->n_cus, st);
-            if (can_qlong) return crag_launch_scan_qlong(ma, mode, h0->n_cus, st);
+            if (can_qlong) return crag_launch_scan_qlong(ma, h0->dtype, mode, h0->n_cus, st);
             return crag_launch_scan_qf32(ma, mode, h0->n_cus, st);
         };
         // level 0: dense sample of rows [0, n0) -> tau0; its rows at or below tau0 seed the candidate buffers
@@ -889,7 +890,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
                 ma.progress = nullptr;
                 if (segmented ? crag_launch_scan_qreg2(ma, 1, h0->n_cus, st)
                     : qsplit  ? crag_launch_scan_qsplit(ma, 1, h0->n_cus, st)
-                    : can_qlong ? crag_launch_scan_qlong(ma, 1, h0->n_cus, st)
+                    : can_qlong ? crag_launch_scan_qlong(ma, h0->dtype, 1, h0->n_cus, st)
                               : crag_launch_scan_qf32(ma, 1, h0->n_cus, st))
                     return fail(CRAG_E_HIP, "re-scan launch failed");
             } else {
@@ -1502,7 +1503,6 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     if (path == 2) {
         const bool d_bf16 = h->dtype == CRAG_BF16;
         const bool d_qf32 = !d_bf16 && crag_qf32_supported(h->dim_pad);
-        if (!d_bf16 && !d_qf32) return fail(CRAG_E_INVALID, "mfma path: float32 rows of this length have no MFMA scan");
         MfmaArgs a;
         memset(&a, 0, sizeof(a));
         a.rows = h->rows;
@@ -1518,7 +1518,7 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.sample_stride = stride;
         const bool d_qsplit = d_bf16 && crag_qsplit_supported(h->dim_pad);
         const bool d_qreg2 = d_bf16 && crag_qreg2_supported(h->dim_pad);
-        const bool d_qlong = d_bf16 && crag_qlong_supported(h->dim_pad);
+        const bool d_qlong = crag_qlong_supported(h->dtype, h->dim_pad);
         if (!d_qf32 && !d_qsplit && !d_qreg2 && !d_qlong) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
         rowmajor = true;
         bpad = ((long long)B + 15) / 16 * 16;
@@ -1528,7 +1528,7 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.sample_stride = bpad;
         if (d_qf32     ? crag_launch_scan_qf32(a, 0, h->n_cus, st)
             : d_qsplit ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
-            : d_qlong  ? crag_launch_scan_qlong(a, 0, h->n_cus, st)
+            : d_qlong  ? crag_launch_scan_qlong(a, h->dtype, 0, h->n_cus, st)
                        : crag_launch_scan_qreg2(a, 0, h->n_cus, st))
             return fail(CRAG_E_HIP, "mfma scan launch failed");
     } else {

@@ -142,10 +142,10 @@ bool crag_qreg2_supported(int dim_pad);
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)
 int crag_qreg2_segments(int n_queries, int n_cus);
-// bf16 rows of 1536 / 2048 elements (no query-stationary form fits the registers): 128 rows x 128 queries per
-// workgroup, both operands through LDS; flat candidate buffers, row-major sample: crag_scan_qlong.hip
-bool crag_qlong_supported(int dim_pad);
-int crag_launch_scan_qlong(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// rows too long for a query-stationary form (bf16 1536 / 2048 elements, float32 512 / 768 / 1024): 128 rows x 128
+// queries per workgroup, both operands through LDS; flat candidate buffers, row-major sample: crag_scan_qlong.hip
+bool crag_qlong_supported(int dtype, int dim_pad);
+int crag_launch_scan_qlong(const MfmaArgs& a, int dtype, int mode, int n_cus, hipStream_t s);
 
 
 int crag_launch_row_norms(const void* rows, int dtype, int dim_pad, long long n, float* xnorm, float* max_out,

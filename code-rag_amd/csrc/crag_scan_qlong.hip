@@ -1,4 +1,5 @@
-// Batched scan for bf16 rows LONGER than 1024 elements (dim_pad 1536 / 2048), gfx950.
+// Batched scan for rows too long for the query-stationary scans: bf16 rows of 1536 / 2048 elements and float32
+// rows of 512 / 768 / 1024 elements, gfx950.
 //
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection, for the row
@@ -8,8 +9,11 @@
 // B / 8 times (tools/sweep_auto.py, round 2: 256 queries on 1.3M x 1536 took 16 ms, 15x the 768-element case).
 //
 // Neither operand is stationary: a workgroup owns a tile of 128 corpus rows x 128 queries and walks K in steps of
-// 64 elements; both operands go HBM/L2 -> registers -> LDS (two stages, one barrier per step) and from there
-// as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16.  Corpus rows are the A operand and queries the B operand,
+// 128 bytes per row (64 bf16 / 32 float32 elements); both operands go HBM/L2 -> registers -> LDS (two stages, one
+// barrier per step) and from there as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16 -- or, for float32 rows
+// (the reference's own storage type, embed_ingest.py:93 via Chroma), into four v_mfma_f32_32x32x2_f32 per fragment:
+// lane (row, half) holds elements 4*(2s + half) + e of its row, MFMA e multiplies element e of the A fragment with
+// element e of the B fragment, so both operands see the same k order and no shuffle is needed.  Corpus rows are the A operand and queries the B operand,
 // so the accumulator puts the QUERY on the lane (column = lane & 31) and 16 rows in the lane's registers: tau is
 // one VGPR per lane and the fused filter is 16 compares per accumulator, as in the query-stationary scans.
 // 128-byte LDS rows, XOR swizzle slot = chunk ^ ((row >> 1) & 7): the fragment reads are conflict-free.
@@ -26,10 +30,11 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int QL_TM = 128;  // corpus rows per tile
 constexpr int QL_TN = 128;  // queries per tile
-constexpr int QL_BK = 64;   // k elements per stage (128 bytes per row)
+constexpr int QL_KB = 128;  // bytes of every row per stage
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -42,11 +47,11 @@ __device__ __forceinline__ uint4 load16(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int MODE, bool NT>
-__global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned short* __restrict__ rows,
+template <int DT, int MODE, bool NT>
+__global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __restrict__ rows,
                                                        const float* __restrict__ xnorm, long long row_begin,
-                                                       long long row_end, const unsigned short* __restrict__ queries,
-                                                       int n_queries, int n_qtiles, int dim_pad, int metric,
+                                                       long long row_end, const unsigned char* __restrict__ queries,
+                                                       int n_queries, int n_qtiles, int row_bytes, int metric,
                                                        const float* __restrict__ tau, uint32_t* __restrict__ sample,
                                                        long long sample_stride, unsigned long long* __restrict__ cand,
                                                        uint32_t* __restrict__ cnt) {
@@ -78,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned short* __r
         if (ar >= row_end) ar = row_end - 1;
         int qr = q0 + r;
         if (qr >= n_queries) qr = n_queries - 1;
-        gA[i] = (const uint4*)(rows + ar * dim_pad) + c;
-        gB[i] = (const uint4*)(queries + (long long)qr * dim_pad) + c;
+        gA[i] = (const uint4*)(rows + ar * row_bytes) + c;
+        gB[i] = (const uint4*)(queries + (long long)qr * row_bytes) + c;
         soff[i] = lds_off(r, c);
     }
-    const int KT = dim_pad / QL_BK;
+    const int KT = row_bytes / QL_KB;
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -118,22 +123,31 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned short* __r
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8_t a[2], b[2];
+            if constexpr (DT == CRAG_BF16) {
+                bf16x8_t a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wr * 64 + i * 32 + fr;
-                a[i] = *(const bf16x8_t*)(&lds[cur][0][lds_off(r, 2 * s + fh)]);
+                for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8_t*)(&lds[cur][0][lds_off(wr * 64 + i * 32 + fr, 2 * s + fh)]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8_t*)(&lds[cur][1][lds_off(wc * 64 + j * 32 + fr, 2 * s + fh)]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                f32x4_t a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *(const f32x4_t*)(&lds[cur][0][lds_off(wr * 64 + i * 32 + fr, 2 * s + fh)]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *(const f32x4_t*)(&lds[cur][1][lds_off(wc * 64 + j * 32 + fr, 2 * s + fh)]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wc * 64 + j * 32 + fr;
-                b[j] = *(const bf16x8_t*)(&lds[cur][1][lds_off(r, 2 * s + fh)]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < KT) {
 #pragma unroll
@@ -190,28 +204,38 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned short* __r
     }
 }
 
-template <int MODE, bool NT>
-int launch_one(const MfmaArgs& a, long long blocks, int qtiles, hipStream_t s) {
-    hipLaunchKernelGGL((k_scan_qlong<MODE, NT>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)a.rows,
-                       a.xnorm, a.row_begin, a.row_end, (const unsigned short*)a.queries, a.n_queries, qtiles, a.dim_pad,
-                       a.metric, a.tau, a.sample, a.sample_stride, a.cand, a.cnt);
+template <int DT, int MODE, bool NT>
+int launch_one(const MfmaArgs& a, int esz, long long blocks, int qtiles, hipStream_t s) {
+    hipLaunchKernelGGL((k_scan_qlong<DT, MODE, NT>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned char*)a.rows,
+                       a.xnorm, a.row_begin, a.row_end, (const unsigned char*)a.queries, a.n_queries, qtiles,
+                       a.dim_pad * esz, a.metric, a.tau, a.sample, a.sample_stride, a.cand, a.cnt);
     return (int)hipGetLastError();
 }
 
-}  // namespace
-
-bool crag_qlong_supported(int dim_pad) { return dim_pad > 1024 && dim_pad <= 2048 && dim_pad % QL_BK == 0; }
-
-// sample layout of this kernel: sample[row * sample_stride + query]  (row-major)
-int crag_launch_scan_qlong(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) {
-    (void)n_cus;
-    if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
-    if (a.row_begin % 32 || !crag_qlong_supported(a.dim_pad)) return -1;
+template <int DT>
+int launch_dt(const MfmaArgs& a, int mode, hipStream_t s) {
+    const int esz = DT == CRAG_BF16 ? 2 : 4;
     const long long rtiles = (a.row_end - a.row_begin + QL_TM - 1) / QL_TM;
     const int qtiles = (a.n_queries + QL_TN - 1) / QL_TN;
     const long long blocks = (rtiles + 7) / 8 * 8 * qtiles;
     if (blocks > 0x7fffffffLL) return -1;
     const bool nt = qtiles == 1;  // a row tile read by one workgroup only: keep it out of the L2
-    if (mode == 0) return nt ? launch_one<0, true>(a, blocks, qtiles, s) : launch_one<0, false>(a, blocks, qtiles, s);
-    return nt ? launch_one<1, true>(a, blocks, qtiles, s) : launch_one<1, false>(a, blocks, qtiles, s);
+    if (mode == 0) return nt ? launch_one<DT, 0, true>(a, esz, blocks, qtiles, s) : launch_one<DT, 0, false>(a, esz, blocks, qtiles, s);
+    return nt ? launch_one<DT, 1, true>(a, esz, blocks, qtiles, s) : launch_one<DT, 1, false>(a, esz, blocks, qtiles, s);
+}
+
+}  // namespace
+
+// bf16: 1536 / 2048 elements; float32: 512 / 768 / 1024 elements (shorter rows have query-stationary scans)
+bool crag_qlong_supported(int dtype, int dim_pad) {
+    if (dtype == CRAG_BF16) return dim_pad > 1024 && dim_pad <= 2048 && dim_pad % 64 == 0;
+    return dim_pad > 384 && dim_pad <= 1024 && dim_pad % 32 == 0;
+}
+
+// sample layout of this kernel: sample[row * sample_stride + query]  (row-major)
+int crag_launch_scan_qlong(const MfmaArgs& a, int dtype, int mode, int n_cus, hipStream_t s) {
+    (void)n_cus;
+    if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
+    if (a.row_begin % 32 || !crag_qlong_supported(dtype, a.dim_pad)) return -1;
+    return dtype == CRAG_BF16 ? launch_dt<CRAG_BF16>(a, mode, s) : launch_dt<CRAG_F32>(a, mode, s);
 }

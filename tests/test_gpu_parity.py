@@ -188,6 +188,16 @@ def test_parity_long_bf16_rows(coracle, d, n, nq, top_k, metric, scan):
     assert st["fallback"] == 0
 
 
+@pytest.mark.parametrize("nq,scan", [(24, "gemv"), (25, "mfma")])
+def test_long_f32_rows_switch_over(coracle, nq, scan):
+    """float32 rows longer than 384 elements: GEMV groups up to 24 queries, the LDS-tiled scan from 25 (as for the shorter float32 rows)."""
+    rows, queries, classes, _ = synth_case(7000, 768, "f32", nq, seed=83)
+    col = make_collection(rows, "f32", "l2", None, classes)
+    check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
+    st = col.stats()
+    assert (st["mfma_batches"] >= 1) == (scan == "mfma") and (st["gemv_batches"] >= 1) == (scan == "gemv")
+
+
 def test_long_bf16_rows_duplicates_take_the_fallback_tiers(coracle):
     """Every fallback tier behind the LDS-tiled long-row scan: duplicated vectors at the 2*top_k boundary (tier 1),
     a certified re-scan (tier 1b goes through the same kernel with its refined tau), and a collection of identical rows."""
@@ -214,6 +224,10 @@ def test_long_bf16_rows_duplicates_take_the_fallback_tiers(coracle):
     (100, 3000, 20, 10, "l2"),              # padded to 128
     (190, 4000, 17, 10, "l2"),              # padded to 192
     (384, 40, 9, 10, "l2"),                 # a single ragged tile
+    (768, 9000, 40, 10, "l2"),              # longer than 384 elements: the LDS-tiled scan (crag_scan_qlong.hip)
+    (512, 5000, 130, 100, "ip"),            # two query tiles
+    (1000, 3000, 33, 10, "l2"),             # padded to 1024
+    (768, 127, 9, 200, "l2"),               # less than one row tile
 ])
 def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
     """float32 rows through the v_mfma_f32_32x32x2_f32 scan (crag_scan_qf32.hip)."""
@@ -233,7 +247,8 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               ("bf16", 1024, 20, "mfma"), ("f32", 1024, 2, "gemv"), ("bf16", 256, 33, "mfma"),
                                               ("bf16", 768, 150, "mfma"), ("bf16", 384, 129, "mfma"), ("bf16", 512, 256, "mfma"),
                                               ("bf16", 256, 192, "mfma"), ("bf16", 1000, 140, "mfma"), ("bf16", 1024, 9, "mfma"),
-                                              ("bf16", 1536, 40, "mfma"), ("bf16", 2048, 130, "mfma"), ("bf16", 1500, 3, "mfma")])
+                                              ("bf16", 1536, 40, "mfma"), ("bf16", 2048, 130, "mfma"), ("bf16", 1500, 3, "mfma"),
+                                              ("f32", 768, 40, "mfma"), ("f32", 1024, 130, "mfma"), ("f32", 500, 3, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

@@ -463,10 +463,27 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         for (int base = 0; base < m; base += rpr) {
             const int nr = m - base < rpr ? m - base : rpr;
             __syncthreads();  // the previous round's readers are done
-            for (int idx = tid; idx < nr * chunks; idx += 1024) {
-                const int r = idx / chunks, c = idx - r * chunks;
-                const uint32_t row = (uint32_t)(skeys[base + r] & 0xffffffffull);
-                ((uint4*)stage_r)[idx] = ((const uint4*)D.rows)[(long long)row * chunks + c];
+            // four loads in flight per thread, through the GLOBAL address space: D.rows comes out of the descriptor,
+            // which makes it a generic pointer to the compiler, and FLAT loads are waited for one at a time
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+            const __attribute__((address_space(1))) u32x4_t* grows = (const __attribute__((address_space(1))) u32x4_t*)D.rows;
+            const int total = nr * chunks;
+            for (int idx0 = tid; idx0 < total; idx0 += 4 * 1024) {
+                u32x4_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = idx0 + u * 1024;
+                    if (idx < total) {
+                        const int r = idx / chunks, c = idx - r * chunks;
+                        const uint32_t row = (uint32_t)(skeys[base + r] & 0xffffffffull);
+                        v[u] = grows[(long long)row * chunks + c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = idx0 + u * 1024;
+                    if (idx < total) ((u32x4_t*)stage_r)[idx] = v[u];
+                }
             }
             __syncthreads();
             const int r = tid >> 3, j = tid & 7;
@@ -492,9 +509,9 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         if (rank < a.kc) {
             const uint32_t row = (uint32_t)(k & 0xffffffffull);
             uint32_t flags = 0;
-            if (D.path_class) flags |= (uint32_t)D.path_class[row] & CRAG_FLAG_CLASS_MASK;
+            if (D.path_class) flags |= (uint32_t)((const __attribute__((address_space(1))) unsigned char*)D.path_class)[row] & CRAG_FLAG_CLASS_MASK;
             if (D.name_hash && a.qhash_off) {
-                const unsigned long long h = D.name_hash[row];
+                const unsigned long long h = ((const __attribute__((address_space(1))) unsigned long long*)D.name_hash)[row];
                 int lo = a.qhash_off[q], hi = a.qhash_off[q + 1];
                 if (h != 0ull) {
                     while (lo < hi) {
@@ -752,12 +769,16 @@ __global__ __launch_bounds__(256) void k_exact_keys_b(const QueryDesc* __restric
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // eight elements per step through 16-byte loads (rows and staged queries are zero-padded to dim_pad, a multiple of
     // eight elements, and a padded element adds +0.0, which changes no partial sum)
-    const uint4* __restrict__ rv = (const uint4*)((const char*)rows + (size_t)r * dim_pad * esz);
+    // (global address space spelled out: a pointer read from the descriptor is generic, and FLAT loads serialise)
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const __attribute__((address_space(1))) u32x4_t* __restrict__ rv =
+        (const __attribute__((address_space(1))) u32x4_t*)((const char*)rows + (size_t)r * dim_pad * esz);
     const uint4* __restrict__ qv4 = (const uint4*)query;
     for (int d0 = 0; d0 < dim; d0 += 8) {
         double x[8], y[8];
         if (dtype == CRAG_F32) {
-            const uint4 a0 = qv4[d0 >> 2], a1 = qv4[(d0 >> 2) + 1], b0 = rv[d0 >> 2], b1 = rv[(d0 >> 2) + 1];
+            const uint4 a0 = qv4[d0 >> 2], a1 = qv4[(d0 >> 2) + 1];
+            const u32x4_t b0 = rv[d0 >> 2], b1 = rv[(d0 >> 2) + 1];
             const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -766,7 +787,8 @@ __global__ __launch_bounds__(256) void k_exact_keys_b(const QueryDesc* __restric
                 y[j] = (double)__builtin_bit_cast(float, bw[j]);
             }
         } else {
-            const uint4 a0 = qv4[d0 >> 3], b0 = rv[d0 >> 3];
+            const uint4 a0 = qv4[d0 >> 3];
+            const u32x4_t b0 = rv[d0 >> 3];
             const uint32_t aw[4] = {a0.x, a0.y, a0.z, a0.w}, bw[4] = {b0.x, b0.y, b0.z, b0.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

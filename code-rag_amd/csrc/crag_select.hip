@@ -63,11 +63,14 @@ __global__ __launch_bounds__(256) void k_row_norms(const uint4* __restrict__ row
 // Block-wide selection (1024 threads) over n 32-bit keys read through key(i).  Returns, to every thread,
 // a key T with at least want + 1 keys <= T: the exact want-th smallest (0-based, want < n) unless the
 // histogram bin that holds it is crowded (> KTH_LIST keys, e.g. all keys equal), in which case T is that
-// bin's upper edge.  Selection, not sorting: min/max, a 4096-bin histogram of (key - min) >> shift, a
+// bin's upper edge.  Selection, not sorting: min/max, a 2048-bin histogram of (key - min) >> shift, a
 // block scan to the bin that holds the wanted rank, then the exact rank inside that bin (sparse when the
 // wanted key sits in the tail of the score distribution, as it does here).
 // scratch: KTH_SCRATCH 32-bit words of LDS; the caller's LDS writes of the keys must be fenced by the caller.
-constexpr int KTH_BINS = 4096;
+// 2048 bins: k_kth then needs 64 KiB of keys + 12.2 KiB of scratch = under half a CU's LDS, so two of its
+// 1024-thread blocks share a CU (a batch of 1024 queries runs its selections in two rounds instead of four)
+constexpr int KTH_BINS = 2048;
+constexpr int KTH_BITS = 11;
 constexpr int KTH_LIST = 1024;
 constexpr int KTH_SCRATCH = KTH_BINS + KTH_LIST + 48 + 4;
 template <typename KeyFn>
@@ -105,12 +108,12 @@ __device__ __forceinline__ uint32_t block_select(KeyFn key, int n, uint32_t want
     }
     const uint32_t range = mx - mn;
     const int bits = range ? 32 - __builtin_clz(range) : 0;
-    const int shift = bits > 12 ? bits - 12 : 0;             // (key - mn) >> shift < 4096
+    const int shift = bits > KTH_BITS ? bits - KTH_BITS : 0;  // (key - mn) >> shift < KTH_BINS
     for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(key(i) - mn) >> shift], 1u);
     __syncthreads();
-    // exclusive scan over the bins: thread t owns bins 4t .. 4t+3
-    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-    const uint32_t mine = h0 + h1 + h2 + h3;
+    // exclusive scan over the bins: thread t owns bins 2t and 2t+1
+    const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+    const uint32_t mine = h0 + h1;
     uint32_t inc = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -125,10 +128,8 @@ __device__ __forceinline__ uint32_t block_select(KeyFn key, int n, uint32_t want
     const uint32_t M = want + 1;
     if (exc < M && M <= exc + mine) {  // exactly one thread: the wanted key is in one of its bins
         uint32_t e = exc;
-        int bsel = 4 * tid;
-        if (e + h0 < M) { e += h0; ++bsel;
-            if (e + h1 < M) { e += h1; ++bsel;
-                if (e + h2 < M) { e += h2; ++bsel; } } }
+        int bsel = 2 * tid;
+        if (e + h0 < M) { e += h0; ++bsel; }
         ctl[0] = (uint32_t)bsel;
         ctl[1] = M - e - 1;  // rank of the wanted key inside bin bsel
     }

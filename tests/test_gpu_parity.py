@@ -144,6 +144,8 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (384, 7000, 2, 10, "ip"),
     (512, 5000, 2, 100, "l2"),              # two queries, M > 64: the two-block cascade
     (768, 30011, 3, 10, "l2"),              # three queries: two-block cascade, one partly filled wave
+    (384, 9000, 260, 10, "l2"),             # more than 256 queries on 384- and 512-element rows: the variants with the
+    (512, 7000, 300, 10, "ip"),             # default load policy and the pacing poll, which 256 / 768 above also take
 ])
 def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)
@@ -248,7 +250,10 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               ("bf16", 768, 150, "mfma"), ("bf16", 384, 129, "mfma"), ("bf16", 512, 256, "mfma"),
                                               ("bf16", 256, 192, "mfma"), ("bf16", 1000, 140, "mfma"), ("bf16", 1024, 9, "mfma"),
                                               ("bf16", 1536, 40, "mfma"), ("bf16", 2048, 130, "mfma"), ("bf16", 1500, 3, "mfma"),
-                                              ("f32", 768, 40, "mfma"), ("f32", 1024, 130, "mfma"), ("f32", 500, 3, "mfma")])
+                                              ("f32", 768, 40, "mfma"), ("f32", 1024, 130, "mfma"), ("f32", 500, 3, "mfma"),
+                                              # several query groups per tile stream: the sample kernels without nontemporal DMA
+                                              ("bf16", 256, 300, "mfma"), ("bf16", 384, 300, "mfma"), ("bf16", 512, 257, "mfma"),
+                                              ("bf16", 768, 260, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

@@ -1,6 +1,8 @@
 """Extended seeded fuzz against the C oracle (not part of the test suite; run on the GPU box):
 random shapes through the auto dispatch with injected duplicates / near-duplicates (so that every fallback tier is
-hit), single-collection batches and multi-collection batches, host-buffer and device-buffer entry points.
+hit), single-collection batches and multi-collection batches; symbol names and query texts (R3), path classes (R2),
+symbol_boost values on both sides of the 0.01 threshold (R4); the host-buffer entry point, and with FUZZ_DEVICE=1 the
+device-buffer and the no-alloc entry points compared with it.
 
     python tools/fuzz_more.py [cases] [seed]
 """
@@ -43,6 +45,64 @@ def make_rows(n, d, dtype, dup_mode, seed):
     if dtype == "bf16":
         rows = O.f32_to_bf16_bits(rows)
     return rows
+
+
+def names_for_match(match):
+    """names and query texts that realise a bool matrix match[nq <= 6, n] (as tests/test_gpu_parity.py does)"""
+    nq, n = match.shape
+    pat = np.zeros(n, np.int64)
+    for b in range(nq):
+        pat |= match[b].astype(np.int64) << b
+    names = ["" if p == 0 else f"Sym{int(p):02d}q" for p in pat]
+    texts = []
+    for b in range(nq):
+        used = sorted({names[i].lower() for i in range(n) if (pat[i] >> b) & 1})
+        texts.append("find " + " and ".join(used) + " please")
+    return names, texts
+
+
+DEVICE = os.environ.get("FUZZ_DEVICE") == "1"
+
+
+def check_device_entry_points(col, queries_bits, dtype, top_k, sb, texts, got, tag):
+    """crag_search_device must return what crag_search returned; crag_search_device_noalloc too, within its limits
+    (at most 64 queries; CRAG_E_INEXACT = -6 where a query needs a fallback tier, CRAG_E_LIMIT = -4 beyond its scratch)"""
+    import ctypes as C
+    import torch
+    lib = ch.load()
+    q = torch.from_numpy(queries_bits).cuda() if dtype == "f32" else torch.from_numpy(queries_bits.view(np.int16)).cuda().view(torch.bfloat16)
+    b = q.shape[0]
+    qh = qo = None
+    if texts is not None:
+        hs = [col.symbol_hashes(t) for t in texts]
+        off = np.zeros(b + 1, np.int32)
+        np.cumsum([len(h) for h in hs], out=off[1:])
+        cat = np.concatenate(hs) if off[-1] else np.zeros(1, np.uint64)
+        qh, qo = torch.from_numpy(cat.view(np.int64)).cuda(), torch.from_numpy(off).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for name in ("crag_search_device", "crag_search_device_noalloc"):
+        if name.endswith("noalloc") and b > 64:
+            continue
+        out = (torch.full((b, top_k), -7, dtype=torch.int64, device="cuda"), torch.full((b, top_k), -7.0, dtype=torch.float64, device="cuda"),
+               torch.full((b, top_k), -7.0, dtype=torch.float32, device="cuda"), torch.full((b,), -7, dtype=torch.int32, device="cuda"))
+        rc = getattr(lib, name)(col.handle, C.c_void_p(q.data_ptr()), b, top_k, C.c_double(sb),
+                                C.c_void_p(qh.data_ptr()) if qh is not None else None, C.c_void_p(qo.data_ptr()) if qo is not None else None,
+                                C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()),
+                                C.c_void_p(out[3].data_ptr()), C.c_void_p(st))
+        torch.cuda.synchronize()
+        if rc in (-6, -4) and name.endswith("noalloc"):
+            tot["noalloc_declined"] = tot.get("noalloc_declined", 0) + 1
+            continue
+        if rc != 0:
+            print("ERROR", name, rc, lib.crag_last_error(), tag, flush=True)
+            sys.exit(1)
+        ids, sc, di, cn = (t.cpu().numpy() for t in out)
+        for i in range(b):
+            k = int(cn[i])
+            if not (k == int(got[3][i]) and np.array_equal(ids[i, :k], got[0][i, :k]) and np.array_equal(sc[i, :k], got[1][i, :k])
+                    and np.array_equal(di[i, :k].view(np.uint32), got[2][i, :k].view(np.uint32))):
+                print("MISMATCH", name, tag, "query", i, flush=True)
+                sys.exit(1)
 
 
 def check(got, want, tag):
@@ -88,14 +148,26 @@ for case in range(n_cases):
             queries[:len(pick)] = src
         if dtype == "bf16":
             queries = O.f32_to_bf16_bits(queries)
+        r2 = np.random.default_rng(seed + 3)
+        match, names, texts = None, None, None
+        if r2.random() < 0.5:
+            m = min(nq, 4)
+            match = np.zeros((nq, n), np.uint8)
+            match[:m] = r2.random((m, n)) < r2.choice([0.01, 0.1, 0.6])
+            names, texts = names_for_match(match[:m])
+            texts = texts + ["nothing to see"] * (nq - m)
+        sb = float(r2.choice([2.0, 2.0, 1.0, 0.5, 0.004, 37.5]))   # 0.004: boosted rows fall under the 0.01 threshold
         col = ch.GpuCollection(d, dtype, metric)
-        col.add(rows, path_class=classes)
+        col.add(rows, path_class=classes, **({"names": names} if names is not None else {}))
         col.finalize()
         qf = O.bf16_bits_to_f32(queries) if dtype == "bf16" else queries
-        want = coracle.search_numeric(rows, queries, classes, None, top_k, 2.0, metric)
-        check(col.search(qf, top_k, 2.0), want, (case, dtype, d, n, nq, top_k, metric, dup))
+        want = coracle.search_numeric(rows, queries, classes, match, top_k, sb, metric)
+        got = col.search(qf, top_k, sb, query_texts=texts)
+        check(got, want, (case, dtype, d, n, nq, top_k, metric, dup, sb, match is not None))
+        if DEVICE:
+            check_device_entry_points(col, queries, dtype, top_k, sb, texts, got, (case, dtype, d, n, nq, top_k, metric, dup))
         st = col.stats()
-        for k in tot:
+        for k in ("fallback", "rescan", "exact_scan"):
             tot[k] += st[k]
         col.close()
     else:
@@ -131,7 +203,7 @@ for case in range(n_cases):
             want += coracle.search_numeric(rows, queries[b:b + 1], classes, None, top_k, 2.0, metric, 1_000_000 * i)
         check(got, want, (case, "multi", dtype, d, order, top_k, metric))
         st = cols[order[0]].stats()
-        for k in tot:
+        for k in ("fallback", "rescan", "exact_scan"):
             tot[k] += st[k]
         for c in cols:
             c.close()

@@ -507,7 +507,7 @@ def config_regimes(ch, torch, np, dev):
     # threads, each with its own stream and result tensors; a thread's launch and wait gaps hide behind the
     # other threads' scans (crag_search* is re-entrant on one handle)
     import threading
-    n_thr, per_thr = 4, 50
+    n_thr, per_thr = 4, 200  # 200 each: with 50 the start-up of the threads was 3 % of the timed region
     c2.set_profiling(False)
 
     def client(k, barrier):

@@ -42,3 +42,32 @@ st = torch.cuda.current_stream(0).cuda_stream
 args = [(col._h, qs[i].data_ptr(), 1, 10, C.c_double(2.0), None, None, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
          res[3].data_ptr(), st) for i in range(64)]
 print(f"bare C call: {loop(lambda i: lib.crag_search_device(*args[i % 64])):.1f} us", flush=True)
+
+# the reference's serving model: several threadpool threads on the one handle (api/main.py:166-167)
+import threading
+
+
+def threaded(n_thr, per_thr=200):
+    def client(k, barrier):
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            mine = col.search_device(qs[k], 10, 2.0)
+            s.synchronize()
+            barrier.wait()
+            for i in range(per_thr):
+                col.search_device(qs[(k * 16 + i) % 64], 10, 2.0, out=mine)
+            s.synchronize()
+    bar = threading.Barrier(n_thr + 1)
+    thr = [threading.Thread(target=client, args=(k, bar)) for k in range(n_thr)]
+    for t in thr:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    for t in thr:
+        t.join()
+    return n_thr * per_thr / (time.perf_counter() - t0)
+
+
+col.set_profiling(False)
+for n_thr in (1, 2, 3, 4, 6, 8, 16):
+    print(f"{n_thr:2d} client threads: {threaded(n_thr):8.1f} q/s", flush=True)

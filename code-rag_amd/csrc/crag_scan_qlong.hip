@@ -9,8 +9,8 @@
 // B / 8 times (tools/sweep_auto.py, round 2: 256 queries on 1.3M x 1536 took 16 ms, 15x the 768-element case).
 //
 // Neither operand is stationary: a workgroup owns a tile of 128 corpus rows x 128 queries and walks K in steps of
-// 128 bytes per row (64 bf16 / 32 float32 elements); both operands go HBM/L2 -> registers -> LDS (two stages, one
-// barrier per step) and from there as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16 -- or, for float32 rows
+// 128 bytes per row (64 bf16 / 32 float32 elements); both operands go HBM/L2 -> registers (two steps ahead) -> LDS
+// (two stages, one barrier per step) and from there as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16 -- or, for float32 rows
 // (the reference's own storage type, embed_ingest.py:93 via Chroma), into four v_mfma_f32_32x32x2_f32 per fragment:
 // lane (row, half) holds elements 4*(2s + half) + e of its row, MFMA e multiplies element e of the A fragment with
 // element e of the B fragment, so both operands see the same k order and no shuffle is needed.  Corpus rows are the A operand and queries the B operand,
@@ -97,30 +97,34 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[4], rb[4];
+    // K loop, two steps per trip so that the two register sets are static.  Loads run TWO steps ahead of the
+    // multiplication (a step's 16 MFMAs per wave last ~0.25 us, a corpus load from HBM 1-2 us: with one step of
+    // lookahead and two workgroups per CU only 32 KiB per CU were in flight).  The barrier is the raw s_barrier behind
+    // a wait for this wave's LDS traffic only: __syncthreads() would also drain the loads in flight (vmcnt(0)).
+    const int fr = lane & 31, fh = lane >> 5;  // fragment reads: per k-step s the chunk is 2s + (lane >> 5)
+    uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+    auto load_step = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = load16<NT>(gA[i]);
-        rb[i] = load16<false>(gB[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *(uint4*)(&lds[0][0][soff[i]]) = ra[i];
-        *(uint4*)(&lds[0][1][soff[i]]) = rb[i];
-    }
-    __syncthreads();
-
-    // fragment read offsets (per k-step s the chunk is 2s + (lane>>5))
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = load16<NT>(gA[i] + (kt + 1) * 8);
-                rb[i] = load16<false>(gB[i] + (kt + 1) * 8);
-            }
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = load16<NT>(gA[i] + kt * 8);
+            rb[i] = load16<false>(gB[i] + kt * 8);
         }
+        __builtin_amdgcn_sched_barrier(0);  // the loads are issued HERE, ahead of the step's MFMAs (hipcc sinks them otherwise)
+    };
+    auto store_step = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
+        __builtin_amdgcn_sched_barrier(0);  // ... and their wait + LDS stores stay behind the MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(uint4*)(&lds[buf][0][soff[i]]) = ra[i];
+            *(uint4*)(&lds[buf][1][soff[i]]) = rb[i];
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto multiply = [&](int cur) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if constexpr (DT == CRAG_BF16) {
@@ -149,15 +153,29 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(uint4*)(&lds[cur ^ 1][0][soff[i]]) = ra[i];
-                *(uint4*)(&lds[cur ^ 1][1][soff[i]]) = rb[i];
-            }
-        }
-        __syncthreads();
+    };
+    // KT is even (row_bytes is a multiple of 256, checked by the launcher); everything in the loop is unconditional,
+    // so the two register sets stay where they are (conditional loads made hipcc copy one set into the other)
+    load_step(0, ra0, rb0);
+    load_step(1, ra1, rb1);
+    store_step(0, ra0, rb0);
+    lds_barrier();
+    for (int kt = 0; kt < KT - 2; kt += 2) {
+        // LDS[0] holds step kt; set 1 holds step kt + 1 (maybe still in flight); set 0 is free
+        load_step(kt + 2, ra0, rb0);
+        multiply(0);
+        store_step(1, ra1, rb1);
+        lds_barrier();
+        // LDS[1] holds step kt + 1; set 0 holds step kt + 2; set 1 is free
+        load_step(kt + 3, ra1, rb1);
+        multiply(1);
+        store_step(0, ra0, rb0);
+        lds_barrier();
     }
+    multiply(0);  // step KT - 2 from LDS[0]; set 1 holds the last step
+    store_step(1, ra1, rb1);
+    lds_barrier();
+    multiply(1);
 
     // fused epilogue: query on the lane, 16 corpus rows per accumulator
     const float c2 = metric == CRAG_L2 ? -2.f : -1.f;
@@ -237,5 +255,6 @@ int crag_launch_scan_qlong(const MfmaArgs& a, int dtype, int mode, int n_cus, hi
     (void)n_cus;
     if (a.row_end <= a.row_begin || a.n_queries <= 0) return 0;
     if (a.row_begin % 32 || !crag_qlong_supported(dtype, a.dim_pad)) return -1;
+    if ((a.dim_pad * (dtype == CRAG_BF16 ? 2 : 4)) % (2 * QL_KB)) return -1;  // the K loop takes two 128-byte steps per trip
     return dtype == CRAG_BF16 ? launch_dt<CRAG_BF16>(a, mode, s) : launch_dt<CRAG_F32>(a, mode, s);
 }

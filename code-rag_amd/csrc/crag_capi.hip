@@ -422,7 +422,8 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
 // launch, candidate-buffer memory), so larger batches run as consecutive chunks on the same stream.
 constexpr int CRAG_MAX_CHUNK = 2048;
 // bf16 rows longer than 1024 elements: batches from this size up take crag_scan_qlong.hip instead of GEMV groups
-constexpr int CRAG_QLONG_FROM_F32 = 25;  // float32 MFMA is 16x slower than bf16: four GEMV groups (2.4 ms on 4 GB) against one pass (2.25 ms)
+constexpr int CRAG_QLONG_FROM_F32 = 9;   // float32: two GEMV groups against one pass over a 32-query tile
+constexpr int CRAG_QLONG_F32_SHORT_MAX = 64;  // float32 rows that crag_scan_qf32 takes as well: the tiled scan up to here
 constexpr int CRAG_QLONG_FROM = 9;  // two GEMV groups (3M x 1536: 2.8 ms) against one pass of this scan (1.8 ms)
 int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                    const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
@@ -483,17 +484,21 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     const bool bf16 = h0->dtype == CRAG_BF16;
     const bool can_qreg = bf16 && crag_qreg2_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
     const bool can_qf32 = !bf16 && crag_qf32_supported(h0->dim_pad);
-    const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad);
-    // float32: the MFMA form (up to 128 queries per pass, MFMA-bound at 1.8 TB/s-equivalent) overtakes the GEMV
-    // (8 queries per group at ~4.5 TB/s, groups partly overlapping) where the GEMV needs a fourth group
-    // (tools/sweep_small_batch.py 384 f32: B = 16 2.45 vs 3.40 ms, B = 32 4.66 vs 3.44 ms on 4M rows).
+    // float32 rows up to 384 elements have both the query-stationary scan (128 queries per pass whatever the batch
+    // holds) and the LDS-tiled one (32 / 64 / 128-query tiles): the tiled one up to CRAG_QLONG_F32_SHORT_MAX queries
+    // (a forced "mfma" path keeps the query-stationary scan, a forced "tiled" path takes the tiled one)
+    const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad) &&
+                           (path == 3 || bf16 || !can_qf32 || (path == 0 && B <= CRAG_QLONG_F32_SHORT_MAX));
+    // float32: one GEMV group (up to 8 queries, ~5.3-5.6 TB/s), then the LDS-tiled scan with the narrowest tile that
+    // holds the batch (tools/sweep_auto.py with SWEEP_F32=1, 4 GB of 384-element rows: 9-32 queries 0.74-0.79 ms,
+    // 33-64 queries 1.21 ms; GEMV groups 1.41 ms at 16, the query-stationary form 2.35 ms at any batch up to 128).
     // bf16 rows longer than 1024 elements have no query-stationary form; from CRAG_QLONG_FROM queries up they take the
     // LDS-tiled scan (crag_scan_qlong.hip: corpus read once per 128 queries instead of once per 8); so do float32
     // rows longer than 384 elements from CRAG_QLONG_FROM_F32 queries up.
     // 1024-element rows: the split-K scan with nontemporal DMA is ahead of the GEMV even for ONE query (same box,
     // 1M / 3M / 10M rows: 0.42 vs 0.46, 1.00 vs 1.13, 2.99 vs 3.42 ms); at 768 elements one query is a tie
     const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : CRAG_QLONG_FROM_F32) : can_qf32 ? 25 : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
-    P.mfma = same_handle && (can_qreg || can_qsplit || can_qf32 || can_qlong) && (path == 2 || (path == 0 && B >= mfma_from));
+    P.mfma = same_handle && (can_qreg || can_qsplit || can_qf32 || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
     // (float32 rows, crag_scan_qf32.hip: flat buffers and a row-major sample as well)
@@ -1500,9 +1505,9 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     bool rowmajor = false, tiled = false;
     long long bpad = B;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)std::max<long long>(stride, 1)))) return rc;
-    if (path == 2) {
+    if (path >= 2) {
         const bool d_bf16 = h->dtype == CRAG_BF16;
-        const bool d_qf32 = !d_bf16 && crag_qf32_supported(h->dim_pad);
+        const bool d_qf32 = !d_bf16 && crag_qf32_supported(h->dim_pad) && !(path == 3 && crag_qlong_supported(h->dtype, h->dim_pad));
         MfmaArgs a;
         memset(&a, 0, sizeof(a));
         a.rows = h->rows;
@@ -1595,7 +1600,7 @@ int crag_get_profile(crag_index* h, double* out4, int reset) {
 }
 
 int crag_set_path(crag_index* h, int path) {
-    if (!h || path < 0 || path > 2) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
+    if (!h || path < 0 || path > 3) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
     h->force_path = path;
     return 0;
 }

@@ -33,7 +33,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int QL_TM = 128;  // corpus rows per tile
-constexpr int QL_TN = 128;  // queries per tile
+// queries per tile: TN = 128 (2 x 2 waves of 64 rows x 64 queries), 64 (2 x 2 waves of 64 x 32) or 32 (4 x 1 waves of
+// 32 x 32).  The narrow tiles are for small batches on float32 rows, where the matrix pipe is 16x slower than on bf16:
+// a 128-query tile multiplies 128 columns whatever the batch holds (2.2 ms on 4 GB of rows), a 32-query tile a quarter.
+template <int TN> struct QlGeom;
+template <> struct QlGeom<128> { static constexpr int WC = 2, FI = 2, FJ = 2; };
+template <> struct QlGeom<64> { static constexpr int WC = 2, FI = 2, FJ = 1; };
+template <> struct QlGeom<32> { static constexpr int WC = 1, FI = 1, FJ = 1; };
 constexpr int QL_KB = 128;  // bytes of every row per stage
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -47,7 +53,7 @@ __device__ __forceinline__ uint4 load16(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int DT, int MODE, bool NT>
+template <int DT, int MODE, bool NT, int TN>
 __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __restrict__ rows,
                                                        const float* __restrict__ xnorm, long long row_begin,
                                                        long long row_end, const unsigned char* __restrict__ queries,
@@ -55,11 +61,14 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
                                                        const float* __restrict__ tau, uint32_t* __restrict__ sample,
                                                        long long sample_stride, unsigned long long* __restrict__ cand,
                                                        uint32_t* __restrict__ cnt) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][QL_TM * 128];  // [stage][A|B][16 KiB]
+    constexpr int WC = QlGeom<TN>::WC, FI = QlGeom<TN>::FI, FJ = QlGeom<TN>::FJ;  // wave grid (4 / WC) x WC, FI x FJ fragments each
+    constexpr int NB = TN / 32;  // 16-byte chunks of the query operand per thread and step
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][(QL_TM + TN) * 128];  // [stage]: A 16 KiB, then B
+    constexpr int B_OFF = QL_TM * 128;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     // grid index -> (row tile, query tile): the query tiles of one row tile are 8 blocks apart (same XCD)
     const long long bid = blockIdx.x;
     const long long per = 8LL * n_qtiles;
@@ -69,11 +78,12 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
     const long long rt = grp * 8 + (rem & 7);
     const long long row0 = row_begin + rt * QL_TM;
     if (row0 >= row_end) return;  // the last group of eight row tiles may be ragged (uniform per workgroup)
-    const int q0 = qt * QL_TN;
+    const int q0 = qt * TN;
 
-    // staging geometry: thread handles chunks id = tid + 256*i (i<4): row = id>>3, chunk = id&7
+    // staging geometry: thread handles chunks id = tid + 256*i: row = id>>3, chunk = id&7 (4 per step of the corpus
+    // tile, NB of the query tile)
     const uint4* gA[4];
-    const uint4* gB[4];
+    const uint4* gB[NB];
     int soff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -81,19 +91,21 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
         const int r = id >> 3, c = id & 7;
         long long ar = row0 + r;
         if (ar >= row_end) ar = row_end - 1;
-        int qr = q0 + r;
-        if (qr >= n_queries) qr = n_queries - 1;
         gA[i] = (const uint4*)(rows + ar * row_bytes) + c;
-        gB[i] = (const uint4*)(queries + (long long)qr * row_bytes) + c;
         soff[i] = lds_off(r, c);
+        if (i < NB) {
+            int qr = q0 + r;
+            if (qr >= n_queries) qr = n_queries - 1;
+            gB[i] = (const uint4*)(queries + (long long)qr * row_bytes) + c;
+        }
     }
     const int KT = row_bytes / QL_KB;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[FI][FJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -102,21 +114,21 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
     // lookahead and two workgroups per CU only 32 KiB per CU were in flight).  The barrier is the raw s_barrier behind
     // a wait for this wave's LDS traffic only: __syncthreads() would also drain the loads in flight (vmcnt(0)).
     const int fr = lane & 31, fh = lane >> 5;  // fragment reads: per k-step s the chunk is 2s + (lane >> 5)
-    uint4 ra0[4], rb0[4], ra1[4], rb1[4];
-    auto load_step = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
+    uint4 ra0[4], rb0[NB], ra1[4], rb1[NB];
+    auto load_step = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i] = load16<NT>(gA[i] + kt * 8);
-            rb[i] = load16<false>(gB[i] + kt * 8);
+            if (i < NB) rb[i] = load16<false>(gB[i] + kt * 8);
         }
         __builtin_amdgcn_sched_barrier(0);  // the loads are issued HERE, ahead of the step's MFMAs (hipcc sinks them otherwise)
     };
-    auto store_step = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
+    auto store_step = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[NB]) {
         __builtin_amdgcn_sched_barrier(0);  // ... and their wait + LDS stores stay behind the MFMAs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(uint4*)(&lds[buf][0][soff[i]]) = ra[i];
-            *(uint4*)(&lds[buf][1][soff[i]]) = rb[i];
+            *(uint4*)(&lds[buf][soff[i]]) = ra[i];
+            if (i < NB) *(uint4*)(&lds[buf][B_OFF + soff[i]]) = rb[i];
         }
     };
     auto lds_barrier = [&]() {
@@ -128,28 +140,28 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if constexpr (DT == CRAG_BF16) {
-                bf16x8_t a[2], b[2];
+                bf16x8_t a[FI], b[FJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8_t*)(&lds[cur][0][lds_off(wr * 64 + i * 32 + fr, 2 * s + fh)]);
+                for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8_t*)(&lds[cur][lds_off((wr * FI + i) * 32 + fr, 2 * s + fh)]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8_t*)(&lds[cur][1][lds_off(wc * 64 + j * 32 + fr, 2 * s + fh)]);
+                for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8_t*)(&lds[cur][B_OFF + lds_off((wc * FJ + j) * 32 + fr, 2 * s + fh)]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < FJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             } else {
-                f32x4_t a[2], b[2];
+                f32x4_t a[FI], b[FJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *(const f32x4_t*)(&lds[cur][0][lds_off(wr * 64 + i * 32 + fr, 2 * s + fh)]);
+                for (int i = 0; i < FI; ++i) a[i] = *(const f32x4_t*)(&lds[cur][lds_off((wr * FI + i) * 32 + fr, 2 * s + fh)]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = *(const f32x4_t*)(&lds[cur][1][lds_off(wc * 64 + j * 32 + fr, 2 * s + fh)]);
+                for (int j = 0; j < FJ; ++j) b[j] = *(const f32x4_t*)(&lds[cur][B_OFF + lds_off((wc * FJ + j) * 32 + fr, 2 * s + fh)]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < FI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < FJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
         }
@@ -180,13 +192,13 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
     // fused epilogue: query on the lane, 16 corpus rows per accumulator
     const float c2 = metric == CRAG_L2 ? -2.f : -1.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = q0 + wc * 64 + j * 32 + fr;
+    for (int j = 0; j < FJ; ++j) {
+        const int q = q0 + (wc * FJ + j) * 32 + fr;
         const bool qok = q < n_queries;
         const float tq = (MODE == 1 && qok) ? tau[q] : -__builtin_inff();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long long mb = row0 + wr * 64 + i * 32 + 4 * fh;
+        for (int i = 0; i < FI; ++i) {
+            const long long mb = row0 + (wr * FI + i) * 32 + 4 * fh;
             float sc[16];
             bool hit = false;
 #pragma unroll
@@ -222,32 +234,44 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
     }
 }
 
-template <int DT, int MODE, bool NT>
+template <int DT, int MODE, bool NT, int TN>
 int launch_one(const MfmaArgs& a, int esz, long long blocks, int qtiles, hipStream_t s) {
-    hipLaunchKernelGGL((k_scan_qlong<DT, MODE, NT>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned char*)a.rows,
+    hipLaunchKernelGGL((k_scan_qlong<DT, MODE, NT, TN>), dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned char*)a.rows,
                        a.xnorm, a.row_begin, a.row_end, (const unsigned char*)a.queries, a.n_queries, qtiles,
                        a.dim_pad * esz, a.metric, a.tau, a.sample, a.sample_stride, a.cand, a.cnt);
     return (int)hipGetLastError();
 }
 
-template <int DT>
-int launch_dt(const MfmaArgs& a, int mode, hipStream_t s) {
+template <int DT, int TN>
+int launch_tn(const MfmaArgs& a, int mode, hipStream_t s) {
     const int esz = DT == CRAG_BF16 ? 2 : 4;
     const long long rtiles = (a.row_end - a.row_begin + QL_TM - 1) / QL_TM;
-    const int qtiles = (a.n_queries + QL_TN - 1) / QL_TN;
+    const int qtiles = (a.n_queries + TN - 1) / TN;
     const long long blocks = (rtiles + 7) / 8 * 8 * qtiles;
     if (blocks > 0x7fffffffLL) return -1;
     const bool nt = qtiles == 1;  // a row tile read by one workgroup only: keep it out of the L2
-    if (mode == 0) return nt ? launch_one<DT, 0, true>(a, esz, blocks, qtiles, s) : launch_one<DT, 0, false>(a, esz, blocks, qtiles, s);
-    return nt ? launch_one<DT, 1, true>(a, esz, blocks, qtiles, s) : launch_one<DT, 1, false>(a, esz, blocks, qtiles, s);
+    if (mode == 0) return nt ? launch_one<DT, 0, true, TN>(a, esz, blocks, qtiles, s) : launch_one<DT, 0, false, TN>(a, esz, blocks, qtiles, s);
+    return nt ? launch_one<DT, 1, true, TN>(a, esz, blocks, qtiles, s) : launch_one<DT, 1, false, TN>(a, esz, blocks, qtiles, s);
+}
+
+template <int DT>
+int launch_dt(const MfmaArgs& a, int mode, hipStream_t s) {
+    // the narrowest tile that takes the whole batch; bf16 batches are HBM-bound up to 64 queries either way, so only
+    // float32 gets the narrow tiles (fewer variants to compile and test)
+    if constexpr (DT == CRAG_F32) {
+        if (a.n_queries <= 32) return launch_tn<DT, 32>(a, mode, s);
+        if (a.n_queries <= 64) return launch_tn<DT, 64>(a, mode, s);
+    }
+    return launch_tn<DT, 128>(a, mode, s);
 }
 
 }  // namespace
 
-// bf16: 1536 / 2048 elements; float32: 512 / 768 / 1024 elements (shorter rows have query-stationary scans)
+// bf16: 1536 / 2048 elements (shorter rows have query-stationary scans); float32: every row length, the caller
+// decides between this scan, the GEMV groups and the query-stationary float32 scan (crag_scan_qf32.hip)
 bool crag_qlong_supported(int dtype, int dim_pad) {
-    if (dtype == CRAG_BF16) return dim_pad > 1024 && dim_pad <= 2048 && dim_pad % 64 == 0;
-    return dim_pad > 384 && dim_pad <= 1024 && dim_pad % 32 == 0;
+    if (dtype == CRAG_BF16) return dim_pad > 1024 && dim_pad <= 2048 && dim_pad % 128 == 0;
+    return dim_pad >= 128 && dim_pad <= 1024 && dim_pad % 64 == 0;  // any float32 row length the index stores
 }
 
 // sample layout of this kernel: sample[row * sample_stride + query]  (row-major)

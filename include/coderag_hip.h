@@ -203,7 +203,8 @@ int crag_merge_rerank_device(int device, const void* entries_dev, int G, int B, 
  * batches, [7] fallback queries that needed the full exact scan, [8] fallback queries that went through the certified
  * re-scan (the rest of [2] were settled by re-scoring their whole candidate buffer) */
 int crag_stats(crag_index* h, int64_t* out9, int reset);
-/* force a path for tests/bench: 0 auto, 1 gemv groups, 2 mfma */
+/* force a path for tests/bench: 0 auto, 1 gemv groups, 2 mfma (the query-stationary scan where the row length has
+ * one), 3 the LDS-tiled mfma scan (bf16 rows of 1536 / 2048 elements, every float32 row length; elsewhere as 2) */
 int crag_set_path(crag_index* h, int path);
 /*
  * Kernel timing for bench.py's roofline line: when on, every search brackets its two scan

@@ -190,14 +190,34 @@ def test_parity_long_bf16_rows(coracle, d, n, nq, top_k, metric, scan):
     assert st["fallback"] == 0
 
 
-@pytest.mark.parametrize("nq,scan", [(24, "gemv"), (25, "mfma")])
-def test_long_f32_rows_switch_over(coracle, nq, scan):
-    """float32 rows longer than 384 elements: GEMV groups up to 24 queries, the LDS-tiled scan from 25 (as for the shorter float32 rows)."""
-    rows, queries, classes, _ = synth_case(7000, 768, "f32", nq, seed=83)
+@pytest.mark.parametrize("d,nq,scan", [(768, 8, "gemv"), (768, 9, "mfma"), (384, 8, "gemv"), (384, 9, "mfma"),
+                                       (384, 33, "mfma"), (384, 64, "mfma"), (384, 65, "mfma"), (128, 20, "mfma"),
+                                       (1000, 50, "mfma"), (512, 129, "mfma")])
+def test_f32_rows_switch_over(coracle, d, nq, scan):
+    """float32 rows: one GEMV group up to 8 queries, then the LDS-tiled scan (32-, 64-, 128-query tiles; from 65
+    queries on rows up to 384 elements the query-stationary float32 scan)."""
+    rows, queries, classes, rng = synth_case(7000, d, "f32", nq, seed=83)
+    match = np.zeros((nq, 7000), np.uint8)
+    match[:2] = rng.random((2, 7000)) < 0.08
+    names, texts = names_for_match(match[:2])
+    texts = texts + ["plain query"] * (nq - 2)
+    col = make_collection(rows, "f32", "l2", names, classes)
+    for top_k in (10, 100):
+        check_against_oracle(coracle, col, rows, queries, classes, match, top_k, 2.0, "l2", texts)
+    st = col.stats()
+    assert (st["mfma_batches"] >= 1) == (scan == "mfma") and (st["gemv_batches"] >= 1) == (scan == "gemv")
+    assert st["fallback"] == 0
+
+
+def test_f32_tiled_scan_duplicates_take_the_fallback_tiers(coracle):
+    n, d, nq = 6000, 384, 24
+    rows, queries, classes, rng = synth_case(n, d, "f32", nq, seed=85)
+    rows[100:400] = rows[7]
+    queries[:4] = rows[7]
     col = make_collection(rows, "f32", "l2", None, classes)
     check_against_oracle(coracle, col, rows, queries, classes, None, 10, 2.0, "l2", None)
     st = col.stats()
-    assert (st["mfma_batches"] >= 1) == (scan == "mfma") and (st["gemv_batches"] >= 1) == (scan == "gemv")
+    assert st["mfma_batches"] >= 1 and st["fallback"] >= 4
 
 
 def test_long_bf16_rows_duplicates_take_the_fallback_tiers(coracle):
@@ -253,7 +273,11 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               ("f32", 768, 40, "mfma"), ("f32", 1024, 130, "mfma"), ("f32", 500, 3, "mfma"),
                                               # several query groups per tile stream: the sample kernels without nontemporal DMA
                                               ("bf16", 256, 300, "mfma"), ("bf16", 384, 300, "mfma"), ("bf16", 512, 257, "mfma"),
-                                              ("bf16", 768, 260, "mfma")])
+                                              ("bf16", 768, 260, "mfma"),
+                                              # the LDS-tiled scan on float32 rows of every length: 32-, 64- and 128-query tiles
+                                              ("f32", 384, 9, "tiled"), ("f32", 384, 40, "tiled"), ("f32", 384, 100, "tiled"),
+                                              ("f32", 128, 33, "tiled"), ("f32", 190, 20, "tiled"), ("f32", 256, 64, "tiled"),
+                                              ("f32", 768, 20, "tiled"), ("f32", 1024, 64, "tiled"), ("f32", 512, 200, "tiled")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

@@ -15,7 +15,7 @@ import coderag_hip as ch
 dev = torch.device("cuda:0")
 corpus_bytes = float(sys.argv[1]) if len(sys.argv) > 1 else 4e9
 g = torch.Generator(device=dev).manual_seed(1)
-for name, dims in (("f32", (384, 512, 768, 1024)), ("bf16", (1536, 2048))) if os.environ.get("SWEEP_LONG") else (("bf16", (256, 384, 512, 768, 1024, 1536, 2048)), ("f32", (128, 192, 256, 384, 512, 768, 1024))):
+for name, dims in (("f32", (128, 384, 768)),) if os.environ.get("SWEEP_F32") else (("f32", (384, 512, 768, 1024)), ("bf16", (1536, 2048))) if os.environ.get("SWEEP_LONG") else (("bf16", (256, 384, 512, 768, 1024, 1536, 2048)), ("f32", (128, 192, 256, 384, 512, 768, 1024))):
     tdt = torch.bfloat16 if name == "bf16" else torch.float32
     esz = 2 if name == "bf16" else 4
     for d in dims:
@@ -32,7 +32,7 @@ for name, dims in (("f32", (384, 512, 768, 1024)), ("bf16", (1536, 2048))) if os
         col.attach_device(rows)
         col.finalize()
         line = []
-        for B in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        for B in ((8, 9, 16, 24, 32, 33, 48, 64, 65, 96, 128, 256) if os.environ.get("SWEEP_F32") else (1, 2, 4, 8, 16, 32, 64, 128, 256)):
             qb = q[:B].contiguous()
             for _ in range(3):
                 res = col.search_device(qb, 10, 2.0)

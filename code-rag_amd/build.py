@@ -16,11 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip", "crag_scan_qlong.hip",
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qlong.hip",
            "crag_select.hip", "crag_capi.hip"]
 INCLUDES = {"crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
-            "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"], "crag_scan_qf32.hip": ["crag_qf32_kloop.inc"]}
-ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_qf32.hip")
+            "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"]}
+ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -73,10 +73,6 @@ def check_qreg2_isa(asm_path):
                              lambda m: 128 if int(m.group(2)) == 48 else None)
 
 
-def check_qf32_isa(asm_path):
-    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qf32ILi\d+ELi\d+E\S*):", 8, lambda m: None)
-
-
 def check_qsplit_isa(asm_path):
     check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qsplitILi\d+ELb[01]E\S*):", 3, lambda m: None)
 
@@ -118,7 +114,6 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"{asm} is missing or older than its sources: the fixed-register check would vouch for other code than {obj}")
     check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
     check_qsplit_isa(os.path.join(OBJ, "crag_scan_qsplit.s"))
-    check_qf32_isa(os.path.join(OBJ, "crag_scan_qf32.s"))
     if jobs or not os.path.exists(LIB):
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -423,7 +423,6 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
 constexpr int CRAG_MAX_CHUNK = 2048;
 // bf16 rows longer than 1024 elements: batches from this size up take crag_scan_qlong.hip instead of GEMV groups
 constexpr int CRAG_QLONG_FROM_F32 = 9;   // float32: two GEMV groups against one pass over a 32-query tile
-constexpr int CRAG_QLONG_F32_SHORT_MAX = 64;  // float32 rows that crag_scan_qf32 takes as well: the tiled scan up to here
 constexpr int CRAG_QLONG_FROM = 9;  // two GEMV groups (3M x 1536: 2.8 ms) against one pass of this scan (1.8 ms)
 int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                    const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
@@ -483,12 +482,10 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     // every query it adds (tools/sweep_small_batch.py: MFMA ahead from B = 2-3 on 384/768/1024-element bf16 rows)
     const bool bf16 = h0->dtype == CRAG_BF16;
     const bool can_qreg = bf16 && crag_qreg2_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
-    const bool can_qf32 = !bf16 && crag_qf32_supported(h0->dim_pad);
-    // float32 rows up to 384 elements have both the query-stationary scan (128 queries per pass whatever the batch
-    // holds) and the LDS-tiled one (32 / 64 / 128-query tiles): the tiled one up to CRAG_QLONG_F32_SHORT_MAX queries
-    // (a forced "mfma" path keeps the query-stationary scan, a forced "tiled" path takes the tiled one)
-    const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad) &&
-                           (path == 3 || bf16 || !can_qf32 || (path == 0 && B <= CRAG_QLONG_F32_SHORT_MAX));
+    // bf16 rows of 1536 / 2048 elements and every float32 row length: the LDS-tiled scan (a query-stationary float32
+    // scan for rows up to 384 elements, hand-scheduled like the bf16 ones, served 25+ queries until round 2; the
+    // tiled scan in plain HIP was 3-10 % ahead of it at every row length and batch size, tools/cmp_f32_scans.py)
+    const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad);
     // float32: one GEMV group (up to 8 queries, ~5.3-5.6 TB/s), then the LDS-tiled scan with the narrowest tile that
     // holds the batch (tools/sweep_auto.py with SWEEP_F32=1, 4 GB of 384-element rows: 9-32 queries 0.74-0.79 ms,
     // 33-64 queries 1.21 ms; GEMV groups 1.41 ms at 16, the query-stationary form 2.35 ms at any batch up to 128).
@@ -497,14 +494,14 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     // rows longer than 384 elements from CRAG_QLONG_FROM_F32 queries up.
     // 1024-element rows: the split-K scan with nontemporal DMA is ahead of the GEMV even for ONE query (same box,
     // 1M / 3M / 10M rows: 0.42 vs 0.46, 1.00 vs 1.13, 2.99 vs 3.42 ms); at 768 elements one query is a tie
-    const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : CRAG_QLONG_FROM_F32) : can_qf32 ? 25 : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
-    P.mfma = same_handle && (can_qreg || can_qsplit || can_qf32 || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
+    const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : CRAG_QLONG_FROM_F32) : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
+    P.mfma = same_handle && (can_qreg || can_qsplit || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
-    // (float32 rows, crag_scan_qf32.hip: flat buffers and a row-major sample as well)
+    // (the LDS-tiled scan, crag_scan_qlong.hip: flat buffers and a row-major sample as well)
     // the two-block MFMA scan appends to per-workgroup segments of the candidate buffers (no atomics); the
-    // one-block forms (1024-element rows, float32 rows) keep flat buffers and returning atomics.  Every
-    // query-stationary scan runs the multi-level cascade in which a level continues where the previous one
+    // one-block form (1024-element rows) and the tiled scan keep flat buffers and returning atomics.  Every
+    // MFMA scan runs the multi-level cascade in which a level continues where the previous one
     // stopped.  (A one-block scan for bf16 rows up to 768 elements served two queries at top-10 until round 2;
     // the two-block cascade was within 1 % of it there, same box, and it went.)
     const bool segmented = P.mfma && can_qreg;
@@ -670,8 +667,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         auto launch_level = [&](int mode) -> int {
             if (segmented) return crag_launch_scan_qreg2(ma, mode, h0->n_cus, st);
             if (qsplit) return crag_launch_scan_qsplit(ma, mode, h0->n_cus, st);
-            if (can_qlong) return crag_launch_scan_qlong(ma, h0->dtype, mode, h0->n_cus, st);
-            return crag_launch_scan_qf32(ma, mode, h0->n_cus, st);
+            return crag_launch_scan_qlong(ma, h0->dtype, mode, h0->n_cus, st);
         };
         // level 0: dense sample of rows [0, n0) -> tau0; its rows at or below tau0 seed the candidate buffers
         const long long N = h0->n_rows, n0 = qd[0].n_sample;
@@ -895,8 +891,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
                 ma.progress = nullptr;
                 if (segmented ? crag_launch_scan_qreg2(ma, 1, h0->n_cus, st)
                     : qsplit  ? crag_launch_scan_qsplit(ma, 1, h0->n_cus, st)
-                    : can_qlong ? crag_launch_scan_qlong(ma, h0->dtype, 1, h0->n_cus, st)
-                              : crag_launch_scan_qf32(ma, 1, h0->n_cus, st))
+                              : crag_launch_scan_qlong(ma, h0->dtype, 1, h0->n_cus, st))
                     return fail(CRAG_E_HIP, "re-scan launch failed");
             } else {
                 // the same groups over all of their rows: descriptors with from[2] = 0 behind the first set
@@ -1507,7 +1502,6 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)B * (size_t)std::max<long long>(stride, 1)))) return rc;
     if (path >= 2) {
         const bool d_bf16 = h->dtype == CRAG_BF16;
-        const bool d_qf32 = !d_bf16 && crag_qf32_supported(h->dim_pad) && !(path == 3 && crag_qlong_supported(h->dtype, h->dim_pad));
         MfmaArgs a;
         memset(&a, 0, sizeof(a));
         a.rows = h->rows;
@@ -1524,15 +1518,14 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         const bool d_qsplit = d_bf16 && crag_qsplit_supported(h->dim_pad);
         const bool d_qreg2 = d_bf16 && crag_qreg2_supported(h->dim_pad);
         const bool d_qlong = crag_qlong_supported(h->dtype, h->dim_pad);
-        if (!d_qf32 && !d_qsplit && !d_qreg2 && !d_qlong) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
+        if (!d_qsplit && !d_qreg2 && !d_qlong) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
         rowmajor = true;
         bpad = ((long long)B + 15) / 16 * 16;
         tiled = d_qreg2;  // crag_launch_scan_qreg2's tile-major sample
         if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)((std::max<long long>(n, 1) + 31) / 32 * 32)))) return rc;
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = bpad;
-        if (d_qf32     ? crag_launch_scan_qf32(a, 0, h->n_cus, st)
-            : d_qsplit ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
+        if (d_qsplit   ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
             : d_qlong  ? crag_launch_scan_qlong(a, h->dtype, 0, h->n_cus, st)
                        : crag_launch_scan_qreg2(a, 0, h->n_cus, st))
             return fail(CRAG_E_HIP, "mfma scan launch failed");

@@ -133,17 +133,14 @@ struct MfmaArgs {
 // same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip
 bool crag_qsplit_supported(int dim_pad);
 int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
-// same contract for FLOAT32 rows (dim_pad 128 / 192 / 256 / 384), v_mfma_f32_32x32x2_f32: crag_scan_qf32.hip
-bool crag_qf32_supported(int dim_pad);
-int crag_launch_scan_qf32(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // bf16 rows of 256 / 384 / 512 / 768 elements, 256 queries per workgroup (two 32-query blocks per wave), segmented
 // candidate buffers, tile-major sample: crag_scan_qreg2.hip
 bool crag_qreg2_supported(int dim_pad);
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)
 int crag_qreg2_segments(int n_queries, int n_cus);
-// rows too long for a query-stationary form (bf16 1536 / 2048 elements, float32 512 / 768 / 1024): 128 rows x 128
-// queries per workgroup, both operands through LDS; flat candidate buffers, row-major sample: crag_scan_qlong.hip
+// bf16 rows too long for a query-stationary form (1536 / 2048 elements) and float32 rows of every length: 128 rows x
+// 32 / 64 / 128 queries per workgroup, both operands through LDS; flat candidate buffers, row-major sample: crag_scan_qlong.hip
 bool crag_qlong_supported(int dtype, int dim_pad);
 int crag_launch_scan_qlong(const MfmaArgs& a, int dtype, int mode, int n_cus, hipStream_t s);
 

@@ -33,11 +33,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int QL_TM = 128;  // corpus rows per tile
-// queries per tile: TN = 128 (2 x 2 waves of 64 rows x 64 queries), 64 (2 x 2 waves of 64 x 32) or 32 (4 x 1 waves of
-// 32 x 32).  The narrow tiles are for small batches on float32 rows, where the matrix pipe is 16x slower than on bf16:
+// queries per tile: TN = 128 (2 x 2 waves of 64 rows x 64 queries), 96 (4 x 1 waves of 32 x 96), 64 (2 x 2 waves of
+// 64 x 32) or 32 (4 x 1 waves of 32 x 32).  The narrow tiles are for small batches on float32 rows, where the matrix pipe is 16x slower than on bf16:
 // a 128-query tile multiplies 128 columns whatever the batch holds (2.2 ms on 4 GB of rows), a 32-query tile a quarter.
 template <int TN> struct QlGeom;
 template <> struct QlGeom<128> { static constexpr int WC = 2, FI = 2, FJ = 2; };
+template <> struct QlGeom<96> { static constexpr int WC = 1, FI = 1, FJ = 3; };
 template <> struct QlGeom<64> { static constexpr int WC = 2, FI = 2, FJ = 1; };
 template <> struct QlGeom<32> { static constexpr int WC = 1, FI = 1, FJ = 1; };
 constexpr int QL_KB = 128;  // bytes of every row per stage
@@ -261,14 +262,14 @@ int launch_dt(const MfmaArgs& a, int mode, hipStream_t s) {
     if constexpr (DT == CRAG_F32) {
         if (a.n_queries <= 32) return launch_tn<DT, 32>(a, mode, s);
         if (a.n_queries <= 64) return launch_tn<DT, 64>(a, mode, s);
+        if (a.n_queries <= 96) return launch_tn<DT, 96>(a, mode, s);
     }
     return launch_tn<DT, 128>(a, mode, s);
 }
 
 }  // namespace
 
-// bf16: 1536 / 2048 elements (shorter rows have query-stationary scans); float32: every row length, the caller
-// decides between this scan, the GEMV groups and the query-stationary float32 scan (crag_scan_qf32.hip)
+// bf16: 1536 / 2048 elements (shorter rows have query-stationary scans); float32: every row length
 bool crag_qlong_supported(int dtype, int dim_pad) {
     if (dtype == CRAG_BF16) return dim_pad > 1024 && dim_pad <= 2048 && dim_pad % 128 == 0;
     return dim_pad >= 128 && dim_pad <= 1024 && dim_pad % 64 == 0;  // any float32 row length the index stores

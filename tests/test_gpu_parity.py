@@ -191,11 +191,10 @@ def test_parity_long_bf16_rows(coracle, d, n, nq, top_k, metric, scan):
 
 
 @pytest.mark.parametrize("d,nq,scan", [(768, 8, "gemv"), (768, 9, "mfma"), (384, 8, "gemv"), (384, 9, "mfma"),
-                                       (384, 33, "mfma"), (384, 64, "mfma"), (384, 65, "mfma"), (128, 20, "mfma"),
+                                       (384, 33, "mfma"), (384, 64, "mfma"), (384, 65, "mfma"), (384, 96, "mfma"), (384, 97, "mfma"), (128, 20, "mfma"),
                                        (1000, 50, "mfma"), (512, 129, "mfma")])
 def test_f32_rows_switch_over(coracle, d, nq, scan):
-    """float32 rows: one GEMV group up to 8 queries, then the LDS-tiled scan (32-, 64-, 128-query tiles; from 65
-    queries on rows up to 384 elements the query-stationary float32 scan)."""
+    """float32 rows: one GEMV group up to 8 queries, then the LDS-tiled scan (32-, 64-, 96-, 128-query tiles)."""
     rows, queries, classes, rng = synth_case(7000, d, "f32", nq, seed=83)
     match = np.zeros((nq, 7000), np.uint8)
     match[:2] = rng.random((2, 7000)) < 0.08
@@ -252,7 +251,7 @@ def test_long_bf16_rows_duplicates_take_the_fallback_tiers(coracle):
     (768, 127, 9, 200, "l2"),               # less than one row tile
 ])
 def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
-    """float32 rows through the v_mfma_f32_32x32x2_f32 scan (crag_scan_qf32.hip)."""
+    """float32 rows through the v_mfma_f32_32x32x2_f32 form of the LDS-tiled scan (crag_scan_qlong.hip), forced."""
     rows, queries, classes, rng = synth_case(n, d, "f32", nq, seed=78)
     match = np.zeros((nq, n), np.uint8)
     match[:4] = rng.random((4, n)) < 0.08
@@ -277,7 +276,8 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               # the LDS-tiled scan on float32 rows of every length: 32-, 64- and 128-query tiles
                                               ("f32", 384, 9, "tiled"), ("f32", 384, 40, "tiled"), ("f32", 384, 100, "tiled"),
                                               ("f32", 128, 33, "tiled"), ("f32", 190, 20, "tiled"), ("f32", 256, 64, "tiled"),
-                                              ("f32", 768, 20, "tiled"), ("f32", 1024, 64, "tiled"), ("f32", 512, 200, "tiled")])
+                                              ("f32", 768, 20, "tiled"), ("f32", 1024, 64, "tiled"), ("f32", 512, 200, "tiled"),
+                                              ("f32", 384, 70, "tiled"), ("f32", 768, 96, "tiled")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

@@ -1,3 +1,6 @@
+"""float32 rows: forced "mfma" against forced "tiled" over row lengths and batch sizes.  On commits up to e15230f this
+compared the query-stationary k_scan_qf32 with the LDS-tiled k_scan_qlong (the tiled scan won everywhere and
+k_scan_qf32 was deleted); since then both names reach the tiled scan and the two columns must agree."""
 import os, sys, time
 sys.path.insert(0, "/root/repo/code-rag_amd")
 import torch

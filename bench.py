@@ -48,8 +48,8 @@ def pmc_traffic(n, d, B):
     return pmc_entry(n, d, B).get("bytes")
 
 
-def scan_kernel_name(d, B, path):
-    """The scan the library's auto dispatch takes for bf16 rows of d elements and B queries of one collection
+def scan_kernel_name(d, B, path, n=10_000_000, top_k=10):
+    """The scan the library's auto dispatch takes for bf16 rows of d elements, n rows and B queries of one collection
     (crag_capi.hip: search_entries_chunk_launch)."""
     if path == "gemv":
         return "k_scan_gemv"
@@ -57,7 +57,9 @@ def scan_kernel_name(d, B, path):
         return "k_scan_qlong" if (B >= 9 or path == "mfma") else "k_scan_gemv"
     if d > 768:
         return "k_scan_qsplit"
-    return "k_scan_qreg2" if (B >= (2 if d >= 768 else 3) or path == "mfma") else "k_scan_gemv"
+    m = 2 * top_k + max(16, 2 * top_k // 8)
+    first = (1 if n >= 4_000_000 else 2) if d >= 768 else (3 if d >= 512 or m > 64 else 5)
+    return "k_scan_qreg2" if (B >= first or path == "mfma") else "k_scan_gemv"
 
 
 def kernel_sources_sha():
@@ -261,11 +263,11 @@ def main():
     flops = 2.0 * B * scan_rows * d
     achieved_gbs = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     hbm_bound = B < 312                     # 2*B/2 flop per byte vs the ~312 flop/B ridge
-    traffic, traffic_src = (pmc_traffic_checked(n, d, B) if top_k == (100 if B == 1024 else 10) else
-                            (None, "the committed passes are top-10 runs (top-100 at batch 1024)"))
+    traffic, traffic_src = (pmc_traffic_checked(n, d, B) if top_k == (100 if B == 1024 else 10) and (B != 1 or args.path == "gemv") else
+                            (None, "the committed passes are top-10 runs (top-100 at batch 1024; batch 1 with --path gemv)"))
     step_s = ms_per_step * 1e-3
     roofline = {
-        "kernel": scan_kernel_name(d, B, args.path) + " (last cascade level: every row behind the earlier levels)",
+        "kernel": scan_kernel_name(d, B, args.path, n, top_k) + " (last cascade level: every row behind the earlier levels)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(achieved_gbs if hbm_bound else flops / (scan_ms * 1e-3) / 1e12, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF,
@@ -389,7 +391,7 @@ def extra_regimes(col, q, n, d, torch):
     """batch-1 (HBM-bound GEMV) and batch-1024 top-100 (MFMA-bound GEMM) on the same corpus."""
     out = []
     for name, B, top_k, path, steps in (("batch-1 top-10 GEMV", 1, 10, "gemv", 20), ("batch-8 top-10 GEMV", 8, 10, "gemv", 10),
-                                        ("batch-8 top-10 MFMA cascade (what auto picks from 3 queries up)", 8, 10, "mfma", 10),
+                                        ("batch-8 top-10 MFMA cascade (what auto picks)", 8, 10, "mfma", 10),
                                         ("batch-1024 top-100 MFMA", 1024, 100, "mfma", 5),
                                         ("batch-1024 top-10 MFMA", 1024, 10, "mfma", 5)):
         col.set_path(path)

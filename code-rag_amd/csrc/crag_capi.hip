@@ -494,7 +494,13 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     // rows longer than 384 elements from CRAG_QLONG_FROM_F32 queries up.
     // 1024-element rows: the split-K scan with nontemporal DMA is ahead of the GEMV even for ONE query (same box,
     // 1M / 3M / 10M rows: 0.42 vs 0.46, 1.00 vs 1.13, 2.99 vs 3.42 ms); at 768 elements one query is a tie
-    const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : CRAG_QLONG_FROM_F32) : (can_qsplit ? 1 : (h0->dim_pad >= 768 ? 2 : 3));
+    // two-block MFMA cascade against GEMV, bf16, tools/sweep_small_batch.py on 4M rows (ms per batch, GEMV / MFMA):
+    // 256 elements 4 queries 0.43 / 0.49, 6 queries 0.56 / 0.50; 384: 4 queries 0.59 / 0.62, 6 queries 0.83 / 0.62;
+    // 512: 2 queries 0.70 / 0.72, 3 queries 0.74 / 0.72; 768: 1 query 0.99 / 0.96 (10M rows 2.34 / 2.29; the GEMV is
+    // ahead below ~3M rows, where the cascade's two extra launches weigh more), 2 queries 1.04 / 0.96
+    const int qreg2_from = h0->dim_pad >= 768 ? (h0->n_rows >= 4000000 ? 1 : 2) : (h0->dim_pad >= 512 || P.M > 64 ? 3 : 5);
+    // (float32 rows up to 192 elements: the 8-query GEMV variant is VALU-bound there, 0.90-1.0 ms against 0.75 on 4 GB)
+    const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : (h0->dim_pad <= 192 ? 5 : CRAG_QLONG_FROM_F32)) : (can_qsplit ? 1 : qreg2_from);
     P.mfma = same_handle && (can_qreg || can_qsplit || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample

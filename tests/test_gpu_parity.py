@@ -191,10 +191,11 @@ def test_parity_long_bf16_rows(coracle, d, n, nq, top_k, metric, scan):
 
 
 @pytest.mark.parametrize("d,nq,scan", [(768, 8, "gemv"), (768, 9, "mfma"), (384, 8, "gemv"), (384, 9, "mfma"),
-                                       (384, 33, "mfma"), (384, 64, "mfma"), (384, 65, "mfma"), (384, 96, "mfma"), (384, 97, "mfma"), (128, 20, "mfma"),
+                                       (384, 33, "mfma"), (384, 64, "mfma"), (384, 65, "mfma"), (384, 96, "mfma"), (384, 97, "mfma"), (128, 20, "mfma"), (128, 4, "gemv"), (190, 5, "mfma"),
                                        (1000, 50, "mfma"), (512, 129, "mfma")])
 def test_f32_rows_switch_over(coracle, d, nq, scan):
-    """float32 rows: one GEMV group up to 8 queries, then the LDS-tiled scan (32-, 64-, 96-, 128-query tiles)."""
+    """float32 rows: one GEMV group up to 8 queries (4 on rows up to 192 elements), then the LDS-tiled scan (32-, 64-,
+    96-, 128-query tiles)."""
     rows, queries, classes, rng = synth_case(7000, d, "f32", nq, seed=83)
     match = np.zeros((nq, 7000), np.uint8)
     match[:2] = rng.random((2, 7000)) < 0.08

@@ -17,8 +17,8 @@ run() { # name, counters ("" = kernel trace), bench args...
 }
 run b256 "" --no-extras --steps 10 --warmup 3
 run b256 "FETCH_SIZE" --no-extras --steps 5 --warmup 2
-run b1 "" --batch 1 --no-extras --steps 10 --warmup 2
-run b1 "FETCH_SIZE" --batch 1 --no-extras --steps 5 --warmup 2
+run b1 "" --batch 1 --path gemv --no-extras --steps 10 --warmup 2
+run b1 "FETCH_SIZE" --batch 1 --path gemv --no-extras --steps 5 --warmup 2
 run b1024 "" --batch 1024 --top-k 100 --no-extras --steps 10 --warmup 2
 run b1024 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --batch 1024 --top-k 100 --no-extras --steps 5 --warmup 2
 mv $O/pmc_b1024 $O/pmc_b1024_mfma

@@ -1,26 +1,29 @@
-// Batched scan for rows too long for the query-stationary scans: bf16 rows of 1536 / 2048 elements and float32
-// rows of 512 / 768 / 1024 elements, gfx950.
+// LDS-tiled batched scan, gfx950: bf16 rows of 1536 / 2048 elements and float32 rows of every length.
 //
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
-// /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection, for the row
-// lengths whose queries do not fit a wave's registers (96 / 128 MFMA fragments per 32 queries = 384 / 512
-// registers before the first accumulator): the query-stationary scans (crag_scan_qreg2 / qsplit) stop at 1024
-// elements, and without this kernel such rows are scanned by GEMV groups of 8 queries, i.e. the corpus is read
-// B / 8 times (tools/sweep_auto.py, round 2: 256 queries on 1.3M x 1536 took 16 ms, 15x the 768-element case).
+// /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection, where no
+// query-stationary scan applies:
+//   * bf16 rows longer than 1024 elements: the queries do not fit a wave's registers (96 / 128 MFMA fragments per 32
+//     queries = 384 / 512 registers before the first accumulator), so crag_scan_qreg2 / qsplit stop at 1024 elements;
+//     GEMV groups of 8 queries read the corpus B / 8 times (tools/sweep_auto.py, round 2: 256 queries on 1.3M x 1536
+//     took 16 ms, 15x the 768-element case);
+//   * float32 rows (the reference's own storage type, embed_ingest.py:93 via Chroma): the float32 matrix pipe is slow
+//     enough (16 passes per v_mfma_f32_32x32x2_f32) that operands fed from LDS keep it busy -- this kernel is 3-10 %
+//     ahead of the hand-scheduled query-stationary float32 scan it replaced.
 //
-// Neither operand is stationary: a workgroup owns a tile of 128 corpus rows x 128 queries and walks K in steps of
+// Neither operand is stationary: a workgroup owns a tile of 128 corpus rows x TN queries and walks K in steps of
 // 128 bytes per row (64 bf16 / 32 float32 elements); both operands go HBM/L2 -> registers (two steps ahead) -> LDS
-// (two stages, one barrier per step) and from there as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16 -- or, for float32 rows
-// (the reference's own storage type, embed_ingest.py:93 via Chroma), into four v_mfma_f32_32x32x2_f32 per fragment:
-// lane (row, half) holds elements 4*(2s + half) + e of its row, MFMA e multiplies element e of the A fragment with
-// element e of the B fragment, so both operands see the same k order and no shuffle is needed.  Corpus rows are the A operand and queries the B operand,
-// so the accumulator puts the QUERY on the lane (column = lane & 31) and 16 rows in the lane's registers: tau is
-// one VGPR per lane and the fused filter is 16 compares per accumulator, as in the query-stationary scans.
+// (two stages, one barrier per step) and from there as ds_read_b128 fragments into v_mfma_f32_32x32x16_bf16 -- or, for
+// float32, into four v_mfma_f32_32x32x2_f32 per fragment: lane (row, half) holds elements 4*(2s + half) + e of its
+// row, MFMA e multiplies element e of the A fragment with element e of the B fragment, so both operands see the same
+// k order and no shuffle is needed.  Corpus rows are the A operand and queries the B operand, so the accumulator puts
+// the QUERY on the lane (column = lane & 31) and 16 rows in the lane's registers: tau is one VGPR per lane and the
+// fused filter is 16 compares per accumulator, as in the query-stationary scans.
 // 128-byte LDS rows, XOR swizzle slot = chunk ^ ((row >> 1) & 7): the fragment reads are conflict-free.
-// Workgroups that share a row tile (B > 128: one per 128 queries) are eight apart in the grid, so they run on the
-// same XCD and the second one finds the tile in that XCD's L2.
+// Workgroups that share a row tile (more queries than one tile holds) are eight apart in the grid, so they run on
+// the same XCD and the second one finds the tile in that XCD's L2.
 //
-// Same contract as the one-block query-stationary scans (MfmaArgs in crag_common.h):
+// Same contract as the one-block query-stationary scan (MfmaArgs in crag_common.h):
 //   MODE 0 (sample): ordered-float score keys to sample[row][Bpad]  (row-major, coalesced over queries)
 //   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's flat candidate buffer
 #include "crag_common.h"
@@ -34,8 +37,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int QL_TM = 128;  // corpus rows per tile
 // queries per tile: TN = 128 (2 x 2 waves of 64 rows x 64 queries), 96 (4 x 1 waves of 32 x 96), 64 (2 x 2 waves of
-// 64 x 32) or 32 (4 x 1 waves of 32 x 32).  The narrow tiles are for small batches on float32 rows, where the matrix pipe is 16x slower than on bf16:
-// a 128-query tile multiplies 128 columns whatever the batch holds (2.2 ms on 4 GB of rows), a 32-query tile a quarter.
+// 64 x 32) or 32 (4 x 1 waves of 32 x 32).  The narrow tiles are for small batches on float32 rows, where the matrix
+// pipe is 16x slower than on bf16: a 128-query tile multiplies 128 columns whatever the batch holds (2.2 ms on 4 GB
+// of rows), a 32-query tile a quarter.
 template <int TN> struct QlGeom;
 template <> struct QlGeom<128> { static constexpr int WC = 2, FI = 2, FJ = 2; };
 template <> struct QlGeom<96> { static constexpr int WC = 1, FI = 1, FJ = 3; };

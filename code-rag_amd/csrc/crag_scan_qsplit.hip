@@ -1,4 +1,4 @@
-// K2 (split-K query-stationary form): MFMA scan for B >= 3 query batches over 1024-element bf16 rows
+// K2 (split-K query-stationary form): MFMA scan for query batches of any size (one query included) over 1024-element bf16 rows
 // (768 < dim_pad <= 1024), gfx950.
 //
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at

@@ -421,9 +421,10 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
 // Batches of any size: the kernels take at most CRAG_MAX_CHUNK queries per launch sequence (query groups per
 // launch, candidate-buffer memory), so larger batches run as consecutive chunks on the same stream.
 constexpr int CRAG_MAX_CHUNK = 2048;
-// bf16 rows longer than 1024 elements: batches from this size up take crag_scan_qlong.hip instead of GEMV groups
-constexpr int CRAG_QLONG_FROM_F32 = 9;   // float32: two GEMV groups against one pass over a 32-query tile
-constexpr int CRAG_QLONG_FROM = 9;  // two GEMV groups (3M x 1536: 2.8 ms) against one pass of this scan (1.8 ms)
+// batches from this size up take the LDS-tiled scan (crag_scan_qlong.hip) instead of GEMV groups: one group of 8 is
+// the GEMV's best case, a second group reads the corpus a second time (table in search_entries_chunk_launch)
+constexpr int CRAG_QLONG_FROM = 9;      // bf16 rows of 1536 / 2048 elements
+constexpr int CRAG_QLONG_FROM_F32 = 9;  // float32 rows
 int search_entries(crag_index* const* hs, bool same_handle, const void* q_dev, int B, int top_k,
                    const uint64_t* qh_dev, const int32_t* qhoff_dev, CragEntry* entries_dev, Workspace* ws,
                    hipStream_t st, const MergeOut* mo = nullptr) {
@@ -477,30 +478,32 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     P.M = P.kc + std::max(16, P.kc / 8);
     if (P.M > CRAG_MAX_M) P.M = CRAG_MAX_M;
 
-    const int path = h0->force_path;
-    // auto: the query-stationary MFMA kernels hold ~5.2-5.7 TB/s from 2 queries up, the GEMV loses bandwidth with
-    // every query it adds (tools/sweep_small_batch.py: MFMA ahead from B = 2-3 on 384/768/1024-element bf16 rows)
+    // ---- which scan: GEMV groups of up to 8 queries, or one of the MFMA scans (one collection per call only) ----
+    //   bf16 up to 768 elements   two-block query-stationary cascade (crag_scan_qreg2.hip)
+    //   bf16 1024 elements        split-K query-stationary scan (crag_scan_qsplit.hip)
+    //   bf16 1536 / 2048, float32 LDS-tiled scan (crag_scan_qlong.hip); a hand-scheduled query-stationary float32 scan
+    //                             served rows up to 384 elements until round 2 -- the tiled scan in plain HIP was 3-10 %
+    //                             ahead of it at every row length and batch size (tools/cmp_f32_scans.py) and it went
+    // The smallest batch that takes the MFMA scan in auto mode, each from a same-box comparison (ms per batch, GEMV / MFMA):
+    //   bf16 256:  5   (tools/sweep_small_batch.py, 4M rows: 4 queries 0.43 / 0.49, 6 queries 0.56 / 0.50)
+    //   bf16 384:  5   (4 queries 0.59 / 0.62, 6 queries 0.83 / 0.62); 3 for both when M > 64 (more appends per GEMV pass)
+    //   bf16 512:  3   (2 queries 0.70 / 0.72, 3 queries 0.74 / 0.72)
+    //   bf16 768:  1 on 4M rows and more (0.99 / 0.96; 10M rows 2.34 / 2.29), else 2 (the cascade's two extra launches
+    //              weigh more on short scans: the GEMV is ahead below ~3M rows; 2 queries 1.04 / 0.96)
+    //   bf16 1024: 1   (nontemporal DMA; 1M / 3M / 10M rows 0.46 / 0.42, 1.13 / 1.00, 3.42 / 2.99)
+    //   bf16 1536 / 2048: 9  (two GEMV groups 2.8 ms against one pass of the tiled scan 1.8 ms on 3M x 1536)
+    //   float32:   9, i.e. one GEMV group at most (tools/cmp_f32_small_batch.py, 4 GB: 384 elements 8 queries 0.75 / 0.74,
+    //              12 queries 1.40 / 0.74); 5 on rows up to 192 elements, where the 8-query GEMV variant is
+    //              VALU-bound (6-8 queries 0.90-1.0 / 0.75)
+    const int path = h0->force_path;  // 0 auto, 1 GEMV, 2 MFMA, 3 tiled MFMA (tests, bench, tools)
     const bool bf16 = h0->dtype == CRAG_BF16;
     const bool can_qreg = bf16 && crag_qreg2_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
-    // bf16 rows of 1536 / 2048 elements and every float32 row length: the LDS-tiled scan (a query-stationary float32
-    // scan for rows up to 384 elements, hand-scheduled like the bf16 ones, served 25+ queries until round 2; the
-    // tiled scan in plain HIP was 3-10 % ahead of it at every row length and batch size, tools/cmp_f32_scans.py)
     const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad);
-    // float32: one GEMV group (up to 8 queries, ~5.3-5.6 TB/s), then the LDS-tiled scan with the narrowest tile that
-    // holds the batch (tools/sweep_auto.py with SWEEP_F32=1, 4 GB of 384-element rows: 9-32 queries 0.74-0.79 ms,
-    // 33-64 queries 1.21 ms; GEMV groups 1.41 ms at 16, the query-stationary form 2.35 ms at any batch up to 128).
-    // bf16 rows longer than 1024 elements have no query-stationary form; from CRAG_QLONG_FROM queries up they take the
-    // LDS-tiled scan (crag_scan_qlong.hip: corpus read once per 128 queries instead of once per 8); so do float32
-    // rows longer than 384 elements from CRAG_QLONG_FROM_F32 queries up.
-    // 1024-element rows: the split-K scan with nontemporal DMA is ahead of the GEMV even for ONE query (same box,
-    // 1M / 3M / 10M rows: 0.42 vs 0.46, 1.00 vs 1.13, 2.99 vs 3.42 ms); at 768 elements one query is a tie
-    // two-block MFMA cascade against GEMV, bf16, tools/sweep_small_batch.py on 4M rows (ms per batch, GEMV / MFMA):
-    // 256 elements 4 queries 0.43 / 0.49, 6 queries 0.56 / 0.50; 384: 4 queries 0.59 / 0.62, 6 queries 0.83 / 0.62;
-    // 512: 2 queries 0.70 / 0.72, 3 queries 0.74 / 0.72; 768: 1 query 0.99 / 0.96 (10M rows 2.34 / 2.29; the GEMV is
-    // ahead below ~3M rows, where the cascade's two extra launches weigh more), 2 queries 1.04 / 0.96
-    const int qreg2_from = h0->dim_pad >= 768 ? (h0->n_rows >= 4000000 ? 1 : 2) : (h0->dim_pad >= 512 || P.M > 64 ? 3 : 5);
-    // (float32 rows up to 192 elements: the 8-query GEMV variant is VALU-bound there, 0.90-1.0 ms against 0.75 on 4 GB)
-    const int mfma_from = can_qlong ? (bf16 ? CRAG_QLONG_FROM : (h0->dim_pad <= 192 ? 5 : CRAG_QLONG_FROM_F32)) : (can_qsplit ? 1 : qreg2_from);
+    int mfma_from;
+    if (can_qsplit) mfma_from = 1;
+    else if (can_qreg) mfma_from = h0->dim_pad >= 768 ? (h0->n_rows >= 4000000 ? 1 : 2) : (h0->dim_pad >= 512 || P.M > 64 ? 3 : 5);
+    else if (bf16) mfma_from = CRAG_QLONG_FROM;
+    else mfma_from = h0->dim_pad <= 192 ? 5 : CRAG_QLONG_FROM_F32;
     P.mfma = same_handle && (can_qreg || can_qsplit || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample

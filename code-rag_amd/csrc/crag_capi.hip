@@ -148,6 +148,21 @@ struct Workspace {
         pinned_status_cap = want;
         return 0;
     }
+    // results of the host-buffer entry points when they are small: the rerank kernel writes them straight into this
+    // pinned, device-visible block (its own allocation: `pinned` below may be regrown by a fallback tier mid-call)
+    void* pinned_out = nullptr;
+    size_t pinned_out_cap = 0;
+    int ensure_pinned_out(size_t bytes) {
+        if (bytes <= pinned_out_cap) return 0;
+        if (pinned_out) (void)hipHostFree(pinned_out);
+        pinned_out = nullptr;
+        pinned_out_cap = 0;
+        const size_t want = bytes * 2 + 4096;
+        hipError_t e = hipHostMalloc(&pinned_out, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(CRAG_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        pinned_out_cap = want;
+        return 0;
+    }
     int ensure_events() {
         for (auto& e : ev)
             if (!e && hipEventCreate(&e) != hipSuccess) return fail(CRAG_E_HIP, "hipEventCreate failed");
@@ -421,6 +436,8 @@ int search_entries_chunk(crag_index* const* hs, bool same_handle, const void* q_
 // Batches of any size: the kernels take at most CRAG_MAX_CHUNK queries per launch sequence (query groups per
 // launch, candidate-buffer memory), so larger batches run as consecutive chunks on the same stream.
 constexpr int CRAG_MAX_CHUNK = 2048;
+// host-buffer entry points: result sets up to this size are written by the GPU straight into pinned host memory
+constexpr size_t CRAG_DIRECT_OUT_BYTES = 256 * 1024;
 // batches from this size up take the LDS-tiled scan (crag_scan_qlong.hip) instead of GEMV groups: one group of 8 is
 // the GEMV's best case, a second group reads the corpus a second time (table in search_entries_chunk_launch)
 constexpr int CRAG_QLONG_FROM = 9;      // bf16 rows of 1536 / 2048 elements
@@ -1094,8 +1111,16 @@ int search_host(crag_index* const* hs, bool same, const float* queries, int B, i
         qh_dev = (const uint64_t*)((char*)ws->qhash.p + hoff);
     }
     if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * kc))) return rc;
-    if ((rc = ws->out.ensure(out_bytes))) return rc;
-    char* o = (char*)ws->out.p;
+    // Small result sets (a /search request is 10 x 20 bytes) are written by the rerank kernel straight into pinned host
+    // memory: the call already waits for the stream by polling (the certificates), so nothing is left to do after it --
+    // a D2H copy plus a parked hipStreamSynchronize behind the search cost 18-20 us per call (tools/latency_small.py).
+    const bool direct = out_bytes <= CRAG_DIRECT_OUT_BYTES;
+    if (direct) {
+        if ((rc = ws->ensure_pinned_out(out_bytes))) return rc;
+    } else if ((rc = ws->out.ensure(out_bytes))) {
+        return rc;
+    }
+    char* o = direct ? (char*)ws->pinned_out : (char*)ws->out.p;
     MergeOut mo;
     mo.symbol_boost = symbol_boost;
     mo.ids = (long long*)o;
@@ -1104,9 +1129,9 @@ int search_host(crag_index* const* hs, bool same, const float* queries, int B, i
     mo.counts = (int*)(o + (size_t)B * top_k * 20);
     rc = search_entries(hs, same, ws->q.p, B, top_k, qh_dev, qo_dev, (CragEntry*)ws->entries.p, ws, st, &mo);
     if (rc) return rc;
-    char* ho = (char*)ws->pinned + o_off;
-    HIPCHK(hipMemcpyAsync(ho, o, out_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    char* ho = direct ? o : (char*)ws->pinned + o_off;
+    if (!direct) HIPCHK(hipMemcpyAsync(ho, o, out_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(stream_wait(st));  // direct: only non-trivial after a fallback re-ran the rerank
     memcpy(out_ids, ho, (size_t)B * top_k * 8);
     memcpy(out_scores, ho + (size_t)B * top_k * 8, (size_t)B * top_k * 8);
     memcpy(out_dist, ho + (size_t)B * top_k * 16, (size_t)B * top_k * 4);

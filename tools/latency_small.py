@@ -40,5 +40,11 @@ for n in (300, 3000, 10_000, 30_000, 100_000, 300_000):
 
     t_dev = loop(lambda i: col.search_device(qs[i % 64], 10, 2.0, out=res))
     t_host = loop(lambda i: col.search(qh[i % 64], 10, 2.0))
-    print(f"n={n:7d}: device buffers {t_dev:7.1f} us   host buffers {t_host:7.1f} us", flush=True)
+    import ctypes as C
+    lib = ch.load()
+    st = torch.cuda.current_stream(0).cuda_stream
+    args = [(col.handle, C.c_void_p(qs[i].data_ptr()), 1, 10, C.c_double(2.0), None, None, C.c_void_p(res[0].data_ptr()),
+             C.c_void_p(res[1].data_ptr()), C.c_void_p(res[2].data_ptr()), C.c_void_p(res[3].data_ptr()), C.c_void_p(st)) for i in range(64)]
+    t_na = loop(lambda i: lib.crag_search_device_noalloc(*args[i % 64]))
+    print(f"n={n:7d}: device buffers {t_dev:7.1f} us   host buffers {t_host:7.1f} us   no-alloc entry point {t_na:7.1f} us", flush=True)
     col.close()

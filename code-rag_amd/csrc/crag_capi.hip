@@ -132,6 +132,11 @@ struct Workspace {
         for (DevBuf* b : {&q, &desc, &tau, &cntst, &segcnt, &sample, &cand, &entries, &qhash, &out, &keys, &misc}) b->arena = a;
     }
     DevBuf q, desc, tau, cntst, segcnt, sample, cand, entries, qhash, out, keys, misc;
+    // host-buffer entry points, one chunk of queries: descriptors, staged queries and symbol hashes lie back to back in
+    // `pinned` and go up in ONE copy into `stage` (three small H2D copies cost a blit kernel and a gap each);
+    // merged_bytes != 0 tells the chunk launcher to send that many bytes and to find its descriptors in `stage`
+    DevBuf stage;
+    size_t merged_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // scan timing (crag_set_profiling)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -601,15 +606,17 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     const bool qreg = P.mfma;  // every MFMA scan writes a query-minor sample: [row][bpad] or tile-major
     const long long bpad = ((long long)B + 15) / 16 * 16;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
-    const QueryDesc* qd_dev = (const QueryDesc*)ws->desc.p;
-    const GroupDesc* gd_dev = (const GroupDesc*)((char*)ws->desc.p + sizeof(QueryDesc) * (size_t)B);
+    const bool merged = !noalloc && ws->merged_bytes != 0;
+    char* desc_dev = merged ? (char*)ws->stage.p : (char*)ws->desc.p;
+    const QueryDesc* qd_dev = (const QueryDesc*)desc_dev;
+    const GroupDesc* gd_dev = (const GroupDesc*)(desc_dev + sizeof(QueryDesc) * (size_t)B);
     if (noalloc) {
         // one collection, so one QueryDesc for all queries and at most B / 8 groups: they travel as kernel arguments
         if ((rc = put_descriptors(qd[0], gd.data(), (int)gd.size(), B, (QueryDesc*)ws->desc.p, (GroupDesc*)gd_dev, st))) return rc;
     } else {
         memcpy(ws->pinned, qd.data(), sizeof(QueryDesc) * (size_t)B);
         if (!gd.empty()) memcpy((char*)ws->pinned + sizeof(QueryDesc) * (size_t)B, gd.data(), sizeof(GroupDesc) * gd.size());
-        HIPCHK(hipMemcpyAsync(ws->desc.p, ws->pinned, desc_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(desc_dev, ws->pinned, merged ? ws->merged_bytes : desc_bytes, hipMemcpyHostToDevice, st));
     }
     uint32_t* cnt = (uint32_t*)ws->cntst.p;
     uint32_t* status = cnt + (size_t)B * CRAG_CNT_STRIDE;  // device-side certificates (exact fallback; no-alloc entry point)
@@ -1020,10 +1027,12 @@ int check_search_args(crag_index* const* hs, int B, int top_k) {
 }
 
 // host queries (float32) -> device, index dtype, padded stride.  Returns device pointer in ws->q.
-int upload_queries(crag_index* h, const float* queries, int B, Workspace* ws, hipStream_t st, size_t pinned_off) {
+// queries (float32, stride dim) -> index dtype, stride dim_pad, zero-padded, at pinned + pinned_off; copy: also send
+// them to ws->q (otherwise they travel with the merged copy of the chunk launcher)
+int upload_queries(crag_index* h, const float* queries, int B, Workspace* ws, hipStream_t st, size_t pinned_off, bool copy) {
     const size_t bytes = (size_t)B * h->dim_pad * h->esz;
     int rc;
-    if ((rc = ws->q.ensure(bytes))) return rc;
+    if (copy && (rc = ws->q.ensure(bytes))) return rc;
     char* stage = (char*)ws->pinned + pinned_off;
     memset(stage, 0, bytes);
     for (int b = 0; b < B; ++b) {
@@ -1035,7 +1044,7 @@ int upload_queries(crag_index* h, const float* queries, int B, Workspace* ws, hi
             for (int d = 0; d < h->dim; ++d) dst[d] = f32_to_bf16(src[d]);
         }
     }
-    HIPCHK(hipMemcpyAsync(ws->q.p, stage, bytes, hipMemcpyHostToDevice, st));
+    if (copy) HIPCHK(hipMemcpyAsync(ws->q.p, stage, bytes, hipMemcpyHostToDevice, st));
     return 0;
 }
 
@@ -1097,18 +1106,30 @@ int search_host(crag_index* const* hs, bool same, const float* queries, int B, i
     const size_t q_off = (desc_reserve + 15) / 16 * 16;
     const size_t h_off = (q_off + qbytes + 15) / 16 * 16;
     const size_t o_off = (h_off + hash_bytes + 15) / 16 * 16;
-    if ((rc = upload_queries(h0, queries, B, ws, st, q_off))) return rc;
+    // one chunk of queries: everything the kernels read from the host goes up in one copy (see Workspace::stage)
+    const bool merged = B <= CRAG_MAX_CHUNK;
+    if (merged && (rc = ws->stage.ensure(o_off))) return rc;
+    if ((rc = upload_queries(h0, queries, B, ws, st, q_off, !merged))) return rc;
+    const void* q_dev = merged ? (const void*)((char*)ws->stage.p + q_off) : ws->q.p;
+    size_t merged_bytes = q_off + qbytes;
     const uint64_t* qh_dev = nullptr;
     const int32_t* qo_dev = nullptr;
     if (any_hash) {
-        if ((rc = ws->qhash.ensure(hash_bytes))) return rc;
         char* stage = (char*)ws->pinned + h_off;
         memcpy(stage, off.data(), off.size() * 4);
         const size_t hoff = (off.size() * 4 + 7) / 8 * 8;
         if (!all_h.empty()) memcpy(stage + hoff, all_h.data(), all_h.size() * 8);
-        HIPCHK(hipMemcpyAsync(ws->qhash.p, stage, hoff + all_h.size() * 8, hipMemcpyHostToDevice, st));
-        qo_dev = (const int32_t*)ws->qhash.p;
-        qh_dev = (const uint64_t*)((char*)ws->qhash.p + hoff);
+        char* hash_dev;
+        if (merged) {
+            hash_dev = (char*)ws->stage.p + h_off;
+            merged_bytes = h_off + hoff + all_h.size() * 8;
+        } else {
+            if ((rc = ws->qhash.ensure(hash_bytes))) return rc;
+            HIPCHK(hipMemcpyAsync(ws->qhash.p, stage, hoff + all_h.size() * 8, hipMemcpyHostToDevice, st));
+            hash_dev = (char*)ws->qhash.p;
+        }
+        qo_dev = (const int32_t*)hash_dev;
+        qh_dev = (const uint64_t*)(hash_dev + hoff);
     }
     if ((rc = ws->entries.ensure(sizeof(CragEntry) * (size_t)B * kc))) return rc;
     // Small result sets (a /search request is 10 x 20 bytes) are written by the rerank kernel straight into pinned host
@@ -1127,7 +1148,9 @@ int search_host(crag_index* const* hs, bool same, const float* queries, int B, i
     mo.scores = (double*)(o + (size_t)B * top_k * 8);
     mo.dist = (float*)(o + (size_t)B * top_k * 16);
     mo.counts = (int*)(o + (size_t)B * top_k * 20);
-    rc = search_entries(hs, same, ws->q.p, B, top_k, qh_dev, qo_dev, (CragEntry*)ws->entries.p, ws, st, &mo);
+    ws->merged_bytes = merged ? merged_bytes : 0;
+    rc = search_entries(hs, same, q_dev, B, top_k, qh_dev, qo_dev, (CragEntry*)ws->entries.p, ws, st, &mo);
+    ws->merged_bytes = 0;
     if (rc) return rc;
     char* ho = direct ? o : (char*)ws->pinned + o_off;
     if (!direct) HIPCHK(hipMemcpyAsync(ho, o, out_bytes, hipMemcpyDeviceToHost, st));

@@ -20,7 +20,7 @@ SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_qsplit.hip", 
            "crag_select.hip", "crag_capi.hip"]
 INCLUDES = {"crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
             "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"]}
-ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip")
+ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_qsplit.hip", "crag_scan_gemv.hip", "crag_scan_qlong.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -77,6 +77,58 @@ def check_qsplit_isa(asm_path):
     check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qsplitILi\d+ELb[01]E\S*):", 3, lambda m: None)
 
 
+def check_streaming_isa(asm_path, kernel_re, n_kernels, min_rolling_wait, swap_nop=None):
+    """Guards against the two code-generation faults round 2 found in the GEMV, on the emitted ISA
+    of every variant of a streaming kernel:
+      * no FLAT loads of row data (a pointer that lost its address space: a pending FLAT load turns every later wait
+        into vmcnt(0), so the wave drains all its loads instead of keeping them rolling);
+      * at least one counted wait `s_waitcnt vmcnt(N)` with N >= min_rolling_wait (the loads do stay in flight);
+      * swap_nop: every v_permlane{16,32}_swap is directly preceded by `s_nop <swap_nop>` -- hipcc inserts no hazard
+        nops inside an asm statement, and a v_dot2c result needs 3 wait states before the swap reads it (4 before it
+        overwrites it); with 2 the last row of a tile got a stale accumulator."""
+    kernel, seen, prev, roll, bad = None, set(), "", {}, []
+    for n, line in enumerate(open(asm_path), 1):
+        m = re.match(kernel_re, line)
+        if m:
+            kernel = m.group(1)
+            seen.add(kernel)
+            roll[kernel] = 0
+            continue
+        if kernel is None:
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        if "s_endpgm" in code:
+            kernel = None
+            continue
+        if code.startswith("flat_load_dwordx"):
+            bad.append(f"{asm_path}:{n}: FLAT load in {kernel}: {code}")
+        w = re.match(r"s_waitcnt vmcnt\((\d+)\)", code)
+        if w:
+            roll[kernel] = max(roll[kernel], int(w.group(1)))
+        if swap_nop is not None and re.match(r"v_permlane(16|32)_swap", code) and prev != f"s_nop {swap_nop}":
+            bad.append(f"{asm_path}:{n}: swap without `s_nop {swap_nop}` in front ({prev!r}) in {kernel}")
+        prev = code
+    if len(seen) != n_kernels:
+        raise RuntimeError(f"check_streaming_isa: expected {n_kernels} kernels in {asm_path}, found {len(seen)}")
+    bad += [f"{asm_path}: {k}: deepest counted wait is vmcnt({v}) < {min_rolling_wait}: loads are not kept in flight"
+            for k, v in roll.items() if v < min_rolling_wait]
+    if bad:
+        raise RuntimeError("check_streaming_isa:\n" + "\n".join(bad[:20]))
+
+
+def check_gemv_isa(asm_path):
+    # 2 dtypes x 7 row widths x 4 query widths; variants with few loads per super-tile still wait with vmcnt >= 3
+    check_streaming_isa(asm_path, r"^(_Z\S*k_scan_gemvILi\d+ELi\d+ELi\d+E\S*):", 56, 3, swap_nop=4)
+
+
+def check_qlong_isa(asm_path):
+    # bf16: 128-query tile; float32: 32 / 64 / 96 / 128; x 2 modes x 2 load policies.  Two K steps of loads in flight:
+    # 4 + TN / 32 per thread and step, so at least vmcnt(5) behind the prefetch of the next step
+    check_streaming_isa(asm_path, r"^(_Z\S*k_scan_qlongILi\d+ELi\d+ELb[01]ELi\d+E\S*):", 20, 5)
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -114,6 +166,8 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"{asm} is missing or older than its sources: the fixed-register check would vouch for other code than {obj}")
     check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
     check_qsplit_isa(os.path.join(OBJ, "crag_scan_qsplit.s"))
+    check_gemv_isa(os.path.join(OBJ, "crag_scan_gemv.s"))
+    check_qlong_isa(os.path.join(OBJ, "crag_scan_qlong.s"))
     if jobs or not os.path.exists(LIB):
         run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -285,3 +285,29 @@ def test_eval_metrics_reproduce_the_committed_report():
     assert E.percentile([10.0, 20.0, 30.0, 40.0], 0.5) == 25.0 and E.percentile([], 0.95) == 0.0 and E.percentile([7.0], 0.95) == 7.0
     boom = E.evaluate_search(lambda q, k, s: (_ for _ in ()).throw(RuntimeError("down")), qa[:1])
     assert boom["search"]["hit@k"] == 0.0                                  # an error counts as no results
+
+
+def test_isa_guards_catch_the_gemv_faults_of_round_2(tmp_path):
+    """build.py refuses a GEMV whose ISA shows one of the two faults found in round 2: a swap
+    too close behind v_dot2c, FLAT row loads, waits that drain every load.  Checked on doctored copies of the listing
+    the build emitted for the library in the tree."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("crag_build", os.path.join(ROOT, "code-rag_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    src = os.path.join(ROOT, "code-rag_amd", "build", "crag_scan_gemv.s")
+    if not os.path.exists(src):
+        pytest.skip("no ISA listing: the library was not built in this tree")
+    text = open(src).read()
+    b.check_gemv_isa(src)
+    doctored = {
+        "nop": text.replace("s_nop 4", "s_nop 1"),
+        "flat": re.sub(r"global_load_dwordx4 (v\[\d+:\d+\]), (v\[\d+:\d+\]), off( nt)?", r"flat_load_dwordx4 \1, \2", text, count=1),
+        "drain": re.sub(r"s_waitcnt vmcnt\(\d+\)", "s_waitcnt vmcnt(0)", text),
+    }
+    for name, t in doctored.items():
+        assert t != text, name
+        f = tmp_path / f"{name}.s"
+        f.write_text(t)
+        with pytest.raises(RuntimeError):
+            b.check_gemv_isa(str(f))

@@ -124,9 +124,9 @@ def check_gemv_isa(asm_path):
 
 
 def check_qlong_isa(asm_path):
-    # bf16: 128-query tile; float32: 32 / 64 / 96 / 128; x 2 modes x 2 load policies.  Two K steps of loads in flight:
+    # 2 dtypes x 4 tile widths x 2 modes x 2 load policies.  Two K steps of loads in flight:
     # 4 + TN / 32 per thread and step, so at least vmcnt(5) behind the prefetch of the next step
-    check_streaming_isa(asm_path, r"^(_Z\S*k_scan_qlongILi\d+ELi\d+ELb[01]ELi\d+E\S*):", 20, 5)
+    check_streaming_isa(asm_path, r"^(_Z\S*k_scan_qlongILi\d+ELi\d+ELb[01]ELi\d+E\S*):", 32, 5)
 
 
 def build(force=False, verbose=True):

@@ -37,9 +37,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int QL_TM = 128;  // corpus rows per tile
 // queries per tile: TN = 128 (2 x 2 waves of 64 rows x 64 queries), 96 (4 x 1 waves of 32 x 96), 64 (2 x 2 waves of
-// 64 x 32) or 32 (4 x 1 waves of 32 x 32).  The narrow tiles are for small batches on float32 rows, where the matrix
-// pipe is 16x slower than on bf16: a 128-query tile multiplies 128 columns whatever the batch holds (2.2 ms on 4 GB
-// of rows), a 32-query tile a quarter.
+// 64 x 32) or 32 (4 x 1 waves of 32 x 32).  A tile multiplies all its columns whatever the batch holds, which is what
+// small float32 batches feel (the float32 matrix pipe is 16x slower than the bf16 one: a 128-query tile costs 2.2 ms
+// on 4 GB of rows, a 32-query tile a quarter); launch_dt picks the width with the fewest columns for the batch.
 template <int TN> struct QlGeom;
 template <> struct QlGeom<128> { static constexpr int WC = 2, FI = 2, FJ = 2; };
 template <> struct QlGeom<96> { static constexpr int WC = 1, FI = 1, FJ = 3; };
@@ -261,14 +261,23 @@ int launch_tn(const MfmaArgs& a, int mode, hipStream_t s) {
 
 template <int DT>
 int launch_dt(const MfmaArgs& a, int mode, hipStream_t s) {
-    // the narrowest tile that takes the whole batch; bf16 batches are HBM-bound up to 64 queries either way, so only
-    // float32 gets the narrow tiles (fewer variants to compile and test)
-    if constexpr (DT == CRAG_F32) {
-        if (a.n_queries <= 32) return launch_tn<DT, 32>(a, mode, s);
-        if (a.n_queries <= 64) return launch_tn<DT, 64>(a, mode, s);
-        if (a.n_queries <= 96) return launch_tn<DT, 96>(a, mode, s);
+    // the tile width that multiplies the fewest columns for this batch (a tile multiplies all of its columns whatever
+    // the batch holds); every tile also stages the 128 corpus rows once more, priced at 16 columns
+    int best = 128;
+    long long cost = (((long long)a.n_queries + 127) / 128) * (128 + 16);
+    for (int tn : {96, 64, 32}) {
+        const long long c = (((long long)a.n_queries + tn - 1) / tn) * (tn + 16);
+        if (c < cost) {
+            cost = c;
+            best = tn;
+        }
     }
-    return launch_tn<DT, 128>(a, mode, s);
+    switch (best) {
+        case 32: return launch_tn<DT, 32>(a, mode, s);
+        case 64: return launch_tn<DT, 64>(a, mode, s);
+        case 96: return launch_tn<DT, 96>(a, mode, s);
+        default: return launch_tn<DT, 128>(a, mode, s);
+    }
 }
 
 }  // namespace

@@ -192,7 +192,7 @@ def test_parity_long_bf16_rows(coracle, d, n, nq, top_k, metric, scan):
 
 @pytest.mark.parametrize("d,nq,scan", [(768, 8, "gemv"), (768, 9, "mfma"), (384, 8, "gemv"), (384, 9, "mfma"),
                                        (384, 33, "mfma"), (384, 64, "mfma"), (384, 65, "mfma"), (384, 96, "mfma"), (384, 97, "mfma"), (128, 20, "mfma"), (128, 4, "gemv"), (190, 5, "mfma"),
-                                       (1000, 50, "mfma"), (512, 129, "mfma")])
+                                       (1000, 50, "mfma"), (512, 129, "mfma"), (384, 160, "mfma"), (768, 192, "mfma")])
 def test_f32_rows_switch_over(coracle, d, nq, scan):
     """float32 rows: one GEMV group up to 8 queries (4 on rows up to 192 elements), then the LDS-tiled scan (32-, 64-,
     96-, 128-query tiles)."""
@@ -278,7 +278,8 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               ("f32", 384, 9, "tiled"), ("f32", 384, 40, "tiled"), ("f32", 384, 100, "tiled"),
                                               ("f32", 128, 33, "tiled"), ("f32", 190, 20, "tiled"), ("f32", 256, 64, "tiled"),
                                               ("f32", 768, 20, "tiled"), ("f32", 1024, 64, "tiled"), ("f32", 512, 200, "tiled"),
-                                              ("f32", 384, 70, "tiled"), ("f32", 768, 96, "tiled")])
+                                              ("f32", 384, 70, "tiled"), ("f32", 768, 96, "tiled"), ("f32", 384, 160, "tiled"),
+                                              ("bf16", 1536, 128, "mfma"), ("bf16", 2048, 20, "mfma"), ("bf16", 1536, 90, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * (2 (dim_pad + 4) |q||x|max + 3 |x|max^2).  Check the scans against fp64 on every

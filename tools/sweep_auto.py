@@ -32,7 +32,7 @@ for name, dims in (("f32", (128, 384, 768)),) if os.environ.get("SWEEP_F32") els
         col.attach_device(rows)
         col.finalize()
         line = []
-        for B in ((8, 9, 16, 24, 32, 33, 48, 64, 65, 96, 128, 256) if os.environ.get("SWEEP_F32") else (1, 2, 4, 8, 16, 32, 64, 128, 256)):
+        for B in ((32, 64, 96, 128, 130, 160, 192, 200, 256, 260, 300, 384) if os.environ.get("SWEEP_F32") else (1, 2, 4, 8, 16, 32, 64, 128, 256)):
             qb = q[:B].contiguous()
             for _ in range(3):
                 res = col.search_device(qb, 10, 2.0)

@@ -24,7 +24,7 @@ SYMBOLS = [
     "crag_index_set_id_base", "crag_index_add", "crag_index_add_device", "crag_index_attach_device",
     "crag_index_set_symbols", "crag_index_finalize", "crag_index_get_rows",
     "crag_hash_name", "crag_hash_names", "crag_symbol_hashes",
-    "crag_search", "crag_search_multi", "crag_search_device", "crag_search_multi_device",
+    "crag_search", "crag_search_multi", "crag_search_multi_hashed", "crag_search_device", "crag_search_multi_device",
     "crag_search_device_noalloc",
     "crag_search_local_device", "crag_merge_rerank_device",
     "crag_stats", "crag_set_path", "crag_set_profiling", "crag_get_profile", "crag_debug_dense_scores",
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     lib.crag_symbol_hashes.argtypes = [vp, C.c_char_p, i64, vp, i32]
     lib.crag_search.argtypes = [vp, vp, i32, i32, f64, C.c_char_p, vp, vp, vp, vp, vp]
     lib.crag_search_multi.argtypes = [vp, vp, i32, i32, f64, C.c_char_p, vp, vp, vp, vp, vp]
+    lib.crag_search_multi_hashed.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp]
     lib.crag_search_device.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]
     lib.crag_search_multi_device.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]
     lib.crag_search_device_noalloc.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]

@@ -216,10 +216,15 @@ class GpuCollection:
         return ids, sc, di, cn
 
     def symbol_hashes(self, query_text: str, cap: int = 256) -> np.ndarray:
+        """Sorted hashes of the chunk names that occur in the lowered query text -- ALL of them: the buffer grows
+        until the library's answer fits (the search takes this list as the query's symbol side)."""
         qb = str(query_text).lower().encode("utf-8", "surrogatepass")
-        out = np.zeros(cap, np.uint64)
-        n = check(self._lib.crag_symbol_hashes(self._h, qb, len(qb), out.ctypes.data, cap), "crag_symbol_hashes")
-        return out[:n]
+        while True:
+            out = np.zeros(cap, np.uint64)
+            n = check(self._lib.crag_symbol_hashes(self._h, qb, len(qb), out.ctypes.data, cap), "crag_symbol_hashes")
+            if n < cap:
+                return out[:n]
+            cap *= 8
 
     def search_device(self, queries, top_k: int = 10, symbol_boost: float = 2.0, q_hashes=None, q_hash_off=None,
                       out=None, stream=None):
@@ -309,8 +314,10 @@ def merge_rerank_device(device: int, entries, n_shards: int, b: int, top_k: int,
 
 
 def search_multi(collections: List[GpuCollection], queries: np.ndarray, top_k: int = 10, symbol_boost: float = 2.0,
-                 query_texts: Optional[Sequence[str]] = None):
-    """One query per collection handle (workspace isolation), one grouped launch."""
+                 query_texts: Optional[Sequence[str]] = None, query_hashes: Optional[Sequence[np.ndarray]] = None):
+    """One query per collection handle (workspace isolation), one grouped launch.  The symbol boost takes either the
+    query texts (hashed by the library) or `query_hashes`: per query the array GpuCollection.symbol_hashes() returned,
+    for a caller that computed them already (HybridSearcher does, to verify them against the names as strings)."""
     lib = _lib.load()
     b = len(collections)
     dim = collections[0].dim
@@ -323,6 +330,20 @@ def search_multi(collections: List[GpuCollection], queries: np.ndarray, top_k: i
     sc = np.empty((b, top_k), np.float64)
     di = np.empty((b, top_k), np.float32)
     cn = np.empty(b, np.int32)
+    if query_hashes is not None:
+        if len(query_hashes) != b:
+            raise ValueError("one hash array per query vector")
+        if b == 1:   # the /search case: no concatenation
+            hoff = np.array([0, len(query_hashes[0])], np.int32)
+            cat = np.ascontiguousarray(query_hashes[0], np.uint64) if hoff[1] else np.zeros(1, np.uint64)
+        else:
+            hoff = np.zeros(b + 1, np.int32)
+            np.cumsum([len(h) for h in query_hashes], out=hoff[1:])
+            cat = np.ascontiguousarray(np.concatenate(query_hashes), np.uint64) if hoff[-1] else np.zeros(1, np.uint64)
+        check(lib.crag_search_multi_hashed(hs, q.ctypes.data, b, int(top_k), float(symbol_boost), cat.ctypes.data,
+                                           hoff.ctypes.data, ids.ctypes.data, sc.ctypes.data, di.ctypes.data,
+                                           cn.ctypes.data), "crag_search_multi_hashed")
+        return ids, sc, di, cn
     buf, off, _ = GpuCollection._qtext(query_texts, b)
     check(lib.crag_search_multi(hs, q.ctypes.data, b, int(top_k), float(symbol_boost), buf, _ptr(off),
                                 ids.ctypes.data, sc.ctypes.data, di.ctypes.data, cn.ctypes.data), "crag_search_multi")

@@ -69,14 +69,17 @@ class ChunkCollection:
     def count(self) -> int:
         return len(self.ids)
 
-    def check_symbol_hashes(self, query: str):
+    def check_symbol_hashes(self, query: str) -> np.ndarray:
         """Rule out 64-bit hash collisions: every name behind a matched
-        hash must really be a substring of the lowered query."""
+        hash must really be a substring of the lowered query.  Returns the query's symbol hashes, which the search
+        then takes as they are (the text is hashed once, not once here and once inside the library)."""
         q_lower = query.lower()
-        for h in self.gpu.symbol_hashes(query):
+        hashes = self.gpu.symbol_hashes(query)
+        for h in hashes:
             for nm in self._bucket.get(int(h), ()):
                 if nm not in q_lower:
                     raise CragError(f"symbol hash collision on {nm!r}; refusing to return a wrong boost")
+        return hashes
 
 
 def group_requests(keys: Sequence[Optional[Tuple]]) -> List[List[int]]:
@@ -202,9 +205,8 @@ class HybridSearcher:
 
     def _search_vectors(self, col: ChunkCollection, vec: np.ndarray, queries: List[str], top_k: int,
                         symbol_boost: float, include_documents: bool) -> List[List[Dict[str, Any]]]:
-        for q in queries:
-            col.check_symbol_hashes(q)
-        ids, scores, _dists, counts = col.gpu.search(vec, top_k=top_k, symbol_boost=symbol_boost, query_texts=queries)
+        hashes = [col.check_symbol_hashes(q) for q in queries]
+        ids, scores, _dists, counts = search_multi([col.gpu] * len(queries), vec, top_k, symbol_boost, query_hashes=hashes)
         return [self._result_dicts(col, ids[b], scores[b], counts[b], include_documents) for b in range(len(queries))]
 
     def search_many(self, queries: Sequence[str], collection_names: Sequence[str], top_k: int = 10,
@@ -225,15 +227,14 @@ class HybridSearcher:
         if not live:
             return out
         vec = np.asarray(embeddings if embeddings is not None else self.ef(list(queries)), np.float32).reshape(n, -1)
-        for i in live:
-            cols[i].check_symbol_hashes(queries[i])
+        hashes = {i: cols[i].check_symbol_hashes(queries[i]) for i in live}
         alive = set(live)
         groups = group_requests([(cols[i].gpu.device, cols[i].gpu.dim, cols[i].gpu.dtype, cols[i].gpu.metric, id(cols[i]))
                                  if i in alive else None for i in range(n)])
 
         def run(idx: List[int]):
             ids, scores, _d, counts = search_multi([cols[i].gpu for i in idx], vec[idx], top_k, symbol_boost,
-                                                   [queries[i] for i in idx])
+                                                   query_hashes=[hashes[i] for i in idx])
             for b, i in enumerate(idx):
                 out[i] = self._result_dicts(cols[i], ids[b], scores[b], counts[b], include_documents)
 

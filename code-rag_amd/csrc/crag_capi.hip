@@ -1069,9 +1069,12 @@ int symbol_hashes_host(const crag_index* h, const unsigned char* q, int64_t len,
     return 0;
 }
 
+// the symbol-boost side of a query is either its lowered text (qtext/qtext_off: hashed here) or the sorted hash list a
+// caller already holds (in_hashes/in_hoff, what crag_symbol_hashes returns -- a wrapper that verifies the hashes against
+// the names as strings has them anyway and need not have the text hashed a second time)
 int search_host(crag_index* const* hs, bool same, const float* queries, int B, int top_k, double symbol_boost,
-                const char* qtext, const int64_t* qtext_off, int64_t* out_ids, double* out_scores, float* out_dist,
-                int32_t* out_counts) {
+                const char* qtext, const int64_t* qtext_off, const uint64_t* in_hashes, const int32_t* in_hoff,
+                int64_t* out_ids, double* out_scores, float* out_dist, int32_t* out_counts) {
     int rc = check_search_args(hs, B, top_k);
     if (rc) return rc;
     if (!queries || !out_ids || !out_scores || !out_dist || !out_counts)
@@ -1095,6 +1098,13 @@ int search_host(crag_index* const* hs, bool same, const float* queries, int B, i
             all_h.insert(all_h.end(), one.begin(), one.end());
             off[(size_t)b + 1] = (int32_t)all_h.size();
         }
+        any_hash = true;
+    } else if (in_hashes && in_hoff) {
+        if (in_hoff[0] != 0) return fail(CRAG_E_INVALID, "search: hash offsets must start at 0");
+        for (int b = 0; b < B; ++b)
+            if (in_hoff[b + 1] < in_hoff[b]) return fail(CRAG_E_INVALID, "search: hash offsets must not decrease");
+        all_h.assign(in_hashes, in_hashes + in_hoff[B]);
+        off.assign(in_hoff, in_hoff + B + 1);
         any_hash = true;
     }
     const size_t qbytes = (size_t)B * h0->dim_pad * h0->esz;
@@ -1398,7 +1408,8 @@ int crag_search(crag_index* h, const float* queries, int B, int top_k, double sy
                 int32_t* out_counts) {
     if (!h || B <= 0) return fail(CRAG_E_INVALID, "crag_search: bad arguments");
     std::vector<crag_index*> hs((size_t)B, h);
-    return search_host(hs.data(), true, queries, B, top_k, symbol_boost, qtext, qtext_off, out_ids, out_scores, out_dist, out_counts);
+    return search_host(hs.data(), true, queries, B, top_k, symbol_boost, qtext, qtext_off, nullptr, nullptr, out_ids, out_scores, out_dist,
+                       out_counts);
 }
 
 int crag_search_multi(crag_index* const* hs, const float* queries, int B, int top_k, double symbol_boost,
@@ -1407,7 +1418,18 @@ int crag_search_multi(crag_index* const* hs, const float* queries, int B, int to
     if (!hs || B <= 0) return fail(CRAG_E_INVALID, "crag_search_multi: bad arguments");
     bool same = true;
     for (int b = 1; b < B; ++b) same = same && hs[b] == hs[0];
-    return search_host(hs, same, queries, B, top_k, symbol_boost, qtext, qtext_off, out_ids, out_scores, out_dist, out_counts);
+    return search_host(hs, same, queries, B, top_k, symbol_boost, qtext, qtext_off, nullptr, nullptr, out_ids, out_scores, out_dist,
+                       out_counts);
+}
+
+int crag_search_multi_hashed(crag_index* const* hs, const float* queries, int B, int top_k, double symbol_boost,
+                             const uint64_t* q_hashes, const int32_t* q_hash_off, int64_t* out_ids, double* out_scores,
+                             float* out_dist, int32_t* out_counts) {
+    if (!hs || B <= 0) return fail(CRAG_E_INVALID, "crag_search_multi_hashed: bad arguments");
+    bool same = true;
+    for (int b = 1; b < B; ++b) same = same && hs[b] == hs[0];
+    return search_host(hs, same, queries, B, top_k, symbol_boost, nullptr, nullptr, q_hashes, q_hash_off, out_ids, out_scores, out_dist,
+                       out_counts);
 }
 
 int crag_search_local_device(crag_index* h, const void* queries_dev, int B, int top_k, const uint64_t* q_hashes_dev,

@@ -138,6 +138,16 @@ int crag_search_multi(crag_index* const* hs, const float* queries, int B, int to
                       const char* qtext, const int64_t* qtext_off, int64_t* out_ids, double* out_scores,
                       float* out_dist, int32_t* out_counts);
 /*
+ * crag_search_multi (and, with B copies of one handle, crag_search) for a caller that already holds each query's
+ * symbol hashes -- q_hashes: the sorted lists crag_symbol_hashes returns, concatenated; q_hash_off: B+1 offsets
+ * starting at 0; both NULL = no symbol boost.  The Python wrapper verifies every matched hash against the chunk names
+ * as strings (`name in q_lower`, hybrid_search.py:114, must not depend on a 64-bit collision), so it has the hashes
+ * before it searches; this entry point saves hashing each query text a second time.
+ */
+int crag_search_multi_hashed(crag_index* const* hs, const float* queries, int B, int top_k, double symbol_boost,
+                             const uint64_t* q_hashes, const int32_t* q_hash_off, int64_t* out_ids,
+                             double* out_scores, float* out_dist, int32_t* out_counts);
+/*
  * Device-buffer form: queries_dev [B][dim] ALREADY in the index dtype; q_hashes_dev /
  * q_hash_off_dev (sorted symbol hashes per query, B+1 offsets) may be NULL; outputs are device
  * arrays shaped as above.  Work is enqueued on `stream` (a hipStream_t, NULL = default stream);

@@ -1094,3 +1094,27 @@ def test_error_codes_through_the_c_abi():
     assert lib.crag_index_add(h3, rows.ctypes.data, 10, None, None, None) == E_STATE
     for hh in (h, h2, h3):
         assert lib.crag_index_destroy(hh) == 0
+
+
+def test_hashed_host_entry_point_equals_the_text_one():
+    """crag_search_multi_hashed (the symbol side of a query as the hash list the caller already holds) returns what
+    crag_search_multi returns for the query texts -- also for a text that names more chunks than symbol_hashes()'s
+    first buffer holds (400 > 256), and for queries without any match."""
+    n, d = 3000, 384
+    rows = O.synth_unit_rows(n, d, 91, "f32")
+    names = [f"sym{i:04d}x" if i < 600 else "" for i in range(n)]
+    col = ch.GpuCollection(d, "f32", "l2")
+    col.add(rows, names=names, path_class=(np.arange(n) % 3).astype(np.uint8))
+    col.finalize()
+    queries = O.synth_unit_rows(5, d, 92, "f32")
+    texts = ["call " + " ".join(f"sym{i:04d}x" for i in range(400)), "only sym0007x here", "nothing", "", "SYM0599X upper"]
+    hashes = [col.symbol_hashes(t) for t in texts]
+    assert len(hashes[0]) == 400 and len(hashes[1]) == 1 and len(hashes[2]) == 0 and len(hashes[4]) == 1
+    want = ch.search_multi([col] * 5, queries, 10, 2.0, query_texts=texts)
+    got = ch.search_multi([col] * 5, queries, 10, 2.0, query_hashes=hashes)
+    single = col.search(queries, 10, 2.0, query_texts=texts)
+    for a, b, c in zip(want, got, single):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    plain = ch.search_multi([col] * 5, queries, 10, 2.0)
+    assert not np.array_equal(plain[1], want[1])     # the boost did something
+    col.close()

@@ -1118,3 +1118,56 @@ def test_hashed_host_entry_point_equals_the_text_one():
     plain = ch.search_multi([col] * 5, queries, 10, 2.0)
     assert not np.array_equal(plain[1], want[1])     # the boost did something
     col.close()
+
+
+def test_concurrent_searches_from_several_threads_are_exact(coracle):
+    """Four host threads at once on two collections, host- and device-buffer entry points, batch sizes on the GEMV, the
+    two-block cascade and the tiled scan, a duplicated vector so that some calls take a fallback tier: every answer
+    equals the oracle's (the workspace pool, pinned staging and candidate buffers are per call).  The long form is
+    tools/fuzz_threads.py."""
+    import threading
+    import torch
+    cols, data = [], []
+    for dtype, d, n in (("f32", 384, 9000), ("bf16", 768, 12000)):
+        rows = O.synth_unit_rows(n, d, 7 + d, dtype)
+        rows[100:140] = rows[99]
+        classes = (np.arange(n) % 3).astype(np.uint8)
+        queries = O.synth_unit_rows(80, d, 8 + d, dtype)
+        queries[5] = rows[99]
+        col = make_collection(rows, dtype, "l2", None, classes)
+        want = coracle.search_numeric(rows, queries, classes, None, 10, 2.0, "l2")
+        qdev = torch.from_numpy(queries).cuda() if dtype == "f32" else torch.from_numpy(queries.view(np.int16)).cuda().view(torch.bfloat16)
+        cols.append(col)
+        data.append((to_f32(queries), qdev, want))
+    errors = []
+
+    def client(k):
+        rng = np.random.default_rng(100 + k)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for it in range(40):
+                c = int(rng.integers(0, 2))
+                qf, qdev, want = data[c]
+                B = int(rng.choice([1, 2, 8, 9, 20, 64]))
+                lo = int(rng.integers(0, 80 - B + 1))
+                if rng.random() < 0.5:
+                    ids, sc, di, cn = cols[c].search(qf[lo:lo + B], 10, 2.0)
+                else:
+                    res = cols[c].search_device(qdev[lo:lo + B].contiguous(), 10, 2.0)
+                    stream.synchronize()
+                    ids, sc, di, cn = (t.cpu().numpy() for t in res)
+                for b in range(B):
+                    wi, ws, wd = want[lo + b]
+                    kk = len(wi)
+                    if not (int(cn[b]) == kk and np.array_equal(ids[b, :kk], wi) and np.array_equal(sc[b, :kk], ws)
+                            and np.array_equal(di[b, :kk].view(np.uint32), wd.view(np.uint32))):
+                        errors.append((k, it, c, B, lo, b))
+                        return
+
+    thr = [threading.Thread(target=client, args=(k,)) for k in range(4)]
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    assert not errors, errors[:3]
+    assert sum(c.stats()["fallback"] for c in cols) > 0

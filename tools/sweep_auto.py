@@ -26,7 +26,7 @@ for name, dims in (("f32", (128, 384, 768)),) if os.environ.get("SWEEP_F32") els
             m = min(step, n - lo)
             x = torch.randn((m, d), generator=g, device=dev, dtype=torch.float32)
             rows[lo:lo + m] = (x / x.norm(dim=1, keepdim=True)).to(tdt)
-        q = torch.randn((256, d), generator=g, device=dev, dtype=torch.float32)
+        q = torch.randn((512, d), generator=g, device=dev, dtype=torch.float32)
         q = (q / q.norm(dim=1, keepdim=True)).to(tdt)
         col = ch.GpuCollection(d, name, "l2", device=0)
         col.attach_device(rows)

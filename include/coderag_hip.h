@@ -17,8 +17,9 @@
  *     + base score + path/symbol boost + filter + sort     crag_search_device (device buffers)
  *     + [:top_k]  (retriever/hybrid_search.py:60-125)
  *   `name in q_lower` (retriever/hybrid_search.py:114)     crag_hash_name(s), crag_symbol_hashes
- *   one collection per workspace, queried concurrently     crag_search_multi (host buffers),
- *     (api/main.py:77-82, retriever/hybrid_search.py:28-39) crag_search_multi_device (device buffers)
+ *   one collection per workspace, queried concurrently     crag_search_multi, crag_search_multi_hashed
+ *     (api/main.py:77-82, retriever/hybrid_search.py:28-39) (host buffers), crag_search_multi_device
+ *                                                          (device buffers)
  *   row-sharded corpus over the GPUs of one node           crag_search_local_device +
  *     (no reference counterpart; north_star)               crag_merge_rerank_device
  *

@@ -146,6 +146,11 @@ def test_parity_gemv_regime(coracle, dtype, d, n, nq, top_k, metric):
     (768, 30011, 3, 10, "l2"),              # three queries: two-block cascade, one partly filled wave
     (384, 9000, 260, 10, "l2"),             # more than 256 queries on 384- and 512-element rows: the variants with the
     (512, 7000, 300, 10, "ip"),             # default load policy and the pacing poll, which 256 / 768 above also take
+    # configs[2]'s own shape: 1024 queries = FOUR query groups per tile stream (the pacing poll over three partners)
+    # and more rows than 16384, so that filter levels of the cascade run; top-100 (M = 225) and top-10
+    (768, 40000, 1024, 100, "l2"),
+    (768, 40000, 1024, 10, "ip"),
+    (768, 40000, 2048, 10, "l2"),           # eight query groups: the most one pacing line serves
 ])
 def test_parity_mfma_regime(coracle, d, n, nq, top_k, metric):
     rows, queries, classes, rng = synth_case(n, d, "bf16", nq, seed=77)
@@ -662,13 +667,108 @@ def test_c2_full_size_batch1(coracle):
     assert col.stats()["fallback"] == 0
 
 
+
+class _LazyTable:
+    """Indexable stand-in for a 156 250-entry Python list (ids / metadatas / documents of a ChunkCollection)."""
+
+    def __init__(self, n, fn):
+        self._n, self._fn = n, fn
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self._fn(int(i))
+
+
+def test_c5_full_size_64_collections_against_the_oracle(coracle, tmp_path):
+    """configs[4] at its full size -- 64 workspace-isolated collections x 156 250 rows x 1024 bf16 (10M rows in all) with
+    Zipf-drawn chunk names and path classes as bench.py builds them, one query per collection, each naming two symbols
+    (one of them the name of a row among the query's own nearest, so that the boost reorders the result) -- through
+    crag_search_multi_device and through HybridSearcher.search_many, against the C oracle per collection."""
+    import torch
+    from coderag_hip.hybrid_search import ChunkCollection  # noqa: F401  (the class search_many serves)
+    ncol, nper, d, top_k, n_sym = 64, 156_250, 1024, 8, 50_000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    sym_names = [f"sym{i}" for i in range(n_sym)]
+    sym_hash, sym_len = ch.hash_names(sym_names)
+    sym_hash_t = torch.from_numpy(sym_hash.view(np.int64)).to(dev)
+    bucket = {int(h): {nm} for h, nm in zip(sym_hash, sym_names)}
+    rng = np.random.default_rng(5)
+    x = torch.randn((ncol, d), generator=g, device=dev, dtype=torch.float32)
+    q_dev = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16).contiguous()
+    q_bits = q_dev.view(torch.int16).cpu().numpy().view(np.uint16)
+    cols, texts, want, host = [], [], [], []
+    for c in range(ncol):
+        x = torch.randn((nper, d), generator=g, device=dev, dtype=torch.float32)
+        rr = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16).contiguous()
+        zipf = (torch.rand((nper,), generator=g, device=dev).pow(3.0) * n_sym).long().clamp_(max=n_sym - 1)
+        nh = sym_hash_t[zipf].contiguous()
+        u = torch.rand((nper,), generator=g, device=dev)
+        pc = torch.where(u < 0.70, 0, torch.where(u < 0.95, 2, 1)).to(torch.uint8).contiguous()
+        col = ch.GpuCollection(d, "bf16", "l2")
+        col.attach_device(rr, nh, pc)
+        col.set_symbols(sym_hash, sym_len)
+        col.finalize()
+        cols.append(col)
+        rows_h = rr.view(torch.int16).cpu().numpy().view(np.uint16)
+        zipf_h, pc_h = zipf.cpu().numpy(), pc.cpu().numpy()
+        near = coracle.knn(rows_h, q_bits[c:c + 1], 2 * top_k, "l2")[0][0]
+        pick = next(int(r) for r in near[3:] if pc_h[r] != 1)     # a candidate behind the third that no path penalty hides
+        text = f"Where is {sym_names[int(zipf_h[pick])].upper()} used together with sym{int(rng.integers(0, n_sym))}?"
+        texts.append(text)
+        named = np.array([i for i, nm in enumerate(sym_names) if nm in text.lower()], np.int64)   # `name in q_lower`
+        assert len(named) >= 2
+        match = np.isin(zipf_h, named)[None, :].astype(np.uint8)
+        (wi, ws, wd), = coracle.search_numeric(rows_h, q_bits[c:c + 1], pc_h, match, top_k, 2.0, "l2")
+        assert match[0][wi].any()                                  # a boosted row made it into the answer
+        want.append((wi, ws, wd))
+        host.append((zipf_h, pc_h))
+        del rows_h, x
+    # (1) the device-buffer entry point: queries and their symbol hashes resident in HBM
+    hashes = [cols[c].symbol_hashes(texts[c]) for c in range(ncol)]
+    off = np.zeros(ncol + 1, np.int32)
+    np.cumsum([len(h) for h in hashes], out=off[1:])
+    qh = torch.from_numpy(np.concatenate(hashes).view(np.int64)).to(dev)
+    qo = torch.from_numpy(off).to(dev)
+    ids, sc, di, cn = [t.cpu().numpy() for t in ch.search_multi_device(cols, q_dev, top_k, 2.0, qh, qo)]
+    for c, (wi, ws, wd) in enumerate(want):
+        k = len(wi)
+        assert int(cn[c]) == k and np.array_equal(ids[c, :k], wi), c
+        assert np.array_equal(sc[c, :k], ws) and np.array_equal(di[c, :k].view(np.uint32), wd.view(np.uint32)), c
+    # (2) the reference's class: one search_many call = one grouped launch over the 64 workspaces
+    qf = O.bf16_bits_to_f32(q_bits)
+    by_text = {t: qf[c] for c, t in enumerate(texts)}
+    hs = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=lambda ts: np.stack([by_text[t] for t in ts]), dtype="bf16")
+    names = []
+    for c in range(ncol):
+        cc = hs.create_collection(f"code_chunks__ws{c:02d}", d, dtype="bf16")
+        cc.gpu.close()
+        cc.gpu = cols[c]
+        zipf_h, pc_h = host[c]
+        cc.ids = _LazyTable(nper, lambda i, c=c: f"{c:02d}-{i}")
+        cc.metadatas = _LazyTable(nper, lambda i, z=zipf_h: {"name": sym_names[int(z[i])]})
+        cc.documents = _LazyTable(nper, lambda i: None)
+        cc._bucket = bucket
+        names.append(cc.name)
+    got = hs.search_many(texts, names, top_k=top_k, symbol_boost=2.0)
+    for c, (wi, ws, wd) in enumerate(want):
+        assert [r["id"] for r in got[c]] == [f"{c:02d}-{int(i)}" for i in wi], c
+        assert [r["score"] for r in got[c]] == [float(s) for s in ws], c
+        assert all(r["metadata"]["name"] == sym_names[int(host[c][0][int(i)])] for r, i in zip(got[c], wi))
+    assert sum(col.stats()["fallback"] for col in cols) == 0
+    for col in cols:
+        col.close()
+
+
 def test_full_size_10m_bf16_properties():
     """BASELINE.json's metric corpus (10M x 768 bf16) is too big for the CPU oracle in a test, so
     check size-independent properties: planted exact copies of the query come back first with
     distance 0 in ascending id order, distances ascend, ids are distinct, and the reported
     distances agree with an fp64 recomputation of the returned rows."""
     import torch
-    n, d, nq, top_k = 10_000_000, 768, 288, 10
+    n, d, nq = 10_000_000, 768, 1024
     g = torch.Generator(device="cuda").manual_seed(1234)
     rows = torch.empty((n, d), dtype=torch.bfloat16, device="cuda")
     for lo in range(0, n, 1_000_000):
@@ -685,11 +785,14 @@ def test_full_size_10m_bf16_properties():
     first4 = {}
     # two-block MFMA cascade with two queries, with one active wave (B = 32) and with a ragged second query group
     # (B = 288), GEMV (B = 4)
-    for path, nb in (("mfma", 2), ("mfma", 32), ("mfma", 288), ("gemv", 4)):
+    # (B = 288), configs[2] itself (B = 1024 at top-100: four paced query groups, six filter levels), GEMV (B = 4)
+    for path, nb, top_k in (("mfma", 2, 10), ("mfma", 32, 10), ("mfma", 288, 10), ("mfma", 1024, 100), ("mfma", 1024, 10),
+                            ("gemv", 4, 10)):
         col.set_path(path)
         qq = q[:nb].contiguous()
         ids, sc, di, cn = [t.cpu().numpy() for t in col.search_device(qq, top_k, 2.0)]
-        first4[(path, nb)] = (ids[:4].copy(), di[:4].copy(), sc[:4].copy())
+        # no metadata columns here, so the score falls with the distance and a top-100 answer starts with the top-10 one
+        first4[(path, nb, top_k)] = (ids[:4, :10].copy(), di[:4, :10].copy(), sc[:4, :10].copy())
         assert list(ids[0, :3]) == sorted(planted) and np.all(di[0, :3] == 0.0) and np.all(sc[0, :3] == 1.0)
         for b in range(len(qq)):
             assert int(cn[b]) == top_k and len(set(ids[b])) == top_k
@@ -702,7 +805,7 @@ def test_full_size_10m_bf16_properties():
         approx = torch.cdist(qq[:2].float(), rows[:2_000_000].float()).pow(2).topk(top_k, largest=False).values
         assert np.all(di[:2, -1] <= approx[:, -1].cpu().numpy() + 1e-5)
     # three independent scan kernels must agree bit for bit on the queries they share
-    ref = first4[("gemv", 4)]
+    ref = first4[("gemv", 4, 10)]
     for key, got in first4.items():
         for a, b in zip(got, ref):
             n_common = min(len(a), len(b))

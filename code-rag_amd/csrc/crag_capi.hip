@@ -129,9 +129,10 @@ struct Workspace {
     Arena* arena = nullptr;  // crag_search_device_noalloc: every buffer below is carved from it, nothing is pinned
     void use_arena(Arena* a) {
         arena = a;
-        for (DevBuf* b : {&q, &desc, &tau, &cntst, &segcnt, &sample, &cand, &entries, &qhash, &out, &keys, &misc}) b->arena = a;
+        for (DevBuf* b : {&q, &qscan, &desc, &tau, &cntst, &segcnt, &sample, &cand, &entries, &qhash, &out, &keys, &misc}) b->arena = a;
     }
     DevBuf q, desc, tau, cntst, segcnt, sample, cand, entries, qhash, out, keys, misc;
+    DevBuf qscan;  // the 16x16x32 scan's B operand: the queries scaled by -2 / -1 (crag_q16_scale_queries)
     // host-buffer entry points, one chunk of queries: descriptors, staged queries and symbol hashes lie back to back in
     // `pinned` and go up in ONE copy into `stage` (three small H2D copies cost a blit kernel and a gap each);
     // merged_bytes != 0 tells the chunk launcher to send that many bytes and to find its descriptors in `stage`
@@ -257,6 +258,7 @@ struct crag_index {
     std::vector<uint8_t> len_present;  // index = byte length
     int max_name_len = 0;
     int force_path = 0;
+    int force_shape = 0;  // 16 / 32: matrix shape of the query-stationary scan for this handle (crag_set_path 4 / 5), 0 = library default
     int n_cus = 256;
     int profiling = 0;
     std::mutex prof_mu;
@@ -354,6 +356,24 @@ long long level1_rows(long long N, long long n0, int M, double direct_max) {
 // (tools/sweep_tunables.sh history in DESIGN.md): at top-10 (M = 36) r between 3 and 6 is flat within 0.5 %, so
 // r ~ 6 (fewest launches), and up to r = 20 it stays within 0.5 % (round 2: a level saved is paid back by the
 // longer last level and its looser threshold); at top-100 (M = 225) r ~ 3 is 1.5-2 % ahead of r ~ 6 and of r ~ 2.
+// which bf16 matrix shape the query-stationary scan of rows up to 768 elements runs in: 16 = v_mfma_f32_16x16x32_bf16
+// (crag_scan_q16.hip), 32 = v_mfma_f32_32x32x16_bf16 (crag_scan_qreg2.hip).  CRAG_MFMA_SHAPE overrides it for A/B runs
+// (read once per process).
+int mfma_shape() {
+    static const int shape = [] {
+        const char* e = getenv("CRAG_MFMA_SHAPE");
+        const int v = e ? atoi(e) : 0;
+        return v == 16 || v == 32 ? v : CRAG_MFMA_SHAPE_DEFAULT;
+    }();
+    return shape;
+}
+// (the selection kernels gather at most 1024 segments per query: 4 x 8 x 32 streams on the 256 CUs of an MI355X)
+bool use_q16(const crag_index* h) { return (h->force_shape ? h->force_shape : mfma_shape()) == 16 && h->n_cus <= 256; }
+int qstat_segments(const crag_index* h, int B) { return use_q16(h) ? crag_q16_segments(B, h->n_cus) : crag_qreg2_segments(B, h->n_cus); }
+int launch_scan_qstat(const crag_index* h, const MfmaArgs& a, int mode, hipStream_t s) {
+    return use_q16(h) ? crag_launch_scan_q16(a, mode, h->n_cus, s) : crag_launch_scan_qreg2(a, mode, h->n_cus, s);
+}
+
 constexpr int CRAG_MAX_LEVELS = 8;
 typedef SmallVec<long long, CRAG_MAX_LEVELS> LevelBounds;
 LevelBounds cascade_bounds(long long N, long long n0, int M) {
@@ -625,9 +645,10 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     unsigned long long* cand = nullptr;
     // no memset of the counters: level 0's selection (k_kth) writes every query's counter -- flat or per segment --
     // when it seeds the buffers, and k_finalize writes every query's status
-    const int n_seg = segmented ? crag_qreg2_segments(B, h0->n_cus) : 0;
-    // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64): the COUNT must stay <= CAP
-    const int seg_cap = segmented ? std::max(64, 2 * CRAG_CAND_CAP / n_seg) : 0;
+    const int n_seg = segmented ? qstat_segments(h0, B) : 0;
+    // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64; >= 32 in the 16x16x32 shape, which has
+    // twice the segments): the COUNT must stay <= CAP
+    const int seg_cap = segmented ? std::max(use_q16(h0) ? 32 : 64, 2 * CRAG_CAND_CAP / n_seg) : 0;
     const long long cand_stride = segmented ? (long long)n_seg * seg_cap : (long long)CRAG_CAND_CAP;
     if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * (size_t)cand_stride))) return rc;
     cand = (unsigned long long*)ws->cand.p;
@@ -660,6 +681,11 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         ma.xnorm = h0->xnorm;
         ma.n_rows = h0->n_rows;
         ma.queries = q_dev;
+        if (segmented && use_q16(h0)) {  // its accumulators are the scores: B operand = -2 q (l2) / -q (ip), once per search
+            if ((rc = ws->qscan.ensure((size_t)B * h0->dim_pad * 2))) return rc;
+            if (crag_q16_scale_queries(q_dev, B, h0->dim_pad, h0->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
+            ma.queries = ws->qscan.p;
+        }
         ma.n_queries = B;
         ma.dim_pad = h0->dim_pad;
         ma.metric = h0->metric;
@@ -698,7 +724,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     double prof_rows = 0.0;  // rows the last (timed) filter launch scans
     if (cascade) {
         auto launch_level = [&](int mode) -> int {
-            if (segmented) return crag_launch_scan_qreg2(ma, mode, h0->n_cus, st);
+            if (segmented) return launch_scan_qstat(h0, ma, mode, st);
             if (qsplit) return crag_launch_scan_qsplit(ma, mode, h0->n_cus, st);
             return crag_launch_scan_qlong(ma, h0->dtype, mode, h0->n_cus, st);
         };
@@ -922,7 +948,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
                 ma.row_begin = 0;
                 ma.row_end = h0->n_rows;
                 ma.progress = nullptr;
-                if (segmented ? crag_launch_scan_qreg2(ma, 1, h0->n_cus, st)
+                if (segmented ? launch_scan_qstat(h0, ma, 1, st)
                     : qsplit  ? crag_launch_scan_qsplit(ma, 1, h0->n_cus, st)
                               : crag_launch_scan_qlong(ma, h0->dtype, 1, h0->n_cus, st))
                     return fail(CRAG_E_HIP, "re-scan launch failed");
@@ -1601,12 +1627,17 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         rowmajor = true;
         bpad = ((long long)B + 15) / 16 * 16;
         tiled = d_qreg2;  // crag_launch_scan_qreg2's tile-major sample
+        if (d_qreg2 && use_q16(h)) {
+            if ((rc = ws->qscan.ensure((size_t)B * h->dim_pad * 2))) return rc;
+            if (crag_q16_scale_queries(q, B, h->dim_pad, h->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
+            a.queries = ws->qscan.p;
+        }
         if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)bpad * (size_t)((std::max<long long>(n, 1) + 31) / 32 * 32)))) return rc;
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = bpad;
         if (d_qsplit   ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
             : d_qlong  ? crag_launch_scan_qlong(a, h->dtype, 0, h->n_cus, st)
-                       : crag_launch_scan_qreg2(a, 0, h->n_cus, st))
+                       : launch_scan_qstat(h, a, 0, st))
             return fail(CRAG_E_HIP, "mfma scan launch failed");
     } else {
         std::vector<GroupDesc> gd;
@@ -1672,8 +1703,9 @@ int crag_get_profile(crag_index* h, double* out4, int reset) {
 }
 
 int crag_set_path(crag_index* h, int path) {
-    if (!h || path < 0 || path > 3) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
-    h->force_path = path;
+    if (!h || path < 0 || path > 5) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
+    h->force_path = path >= 4 ? 2 : path;                 // 4 / 5: the MFMA scans, with the query-stationary one in the
+    h->force_shape = path == 4 ? 16 : path == 5 ? 32 : 0;  // 16x16x32 / 32x32x16 matrix shape (A/B runs, tests)
     return 0;
 }
 

@@ -139,6 +139,14 @@ bool crag_qreg2_supported(int dim_pad);
 int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
 // segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)
 int crag_qreg2_segments(int n_queries, int n_cus);
+// the same scan in the v_mfma_f32_16x16x32_bf16 shape (crag_scan_q16.hip): same contract, FOUR segments per workgroup
+int crag_launch_scan_q16(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+int crag_q16_segments(int n_queries, int n_cus);
+// ... whose MfmaArgs::queries are the caller's queries scaled by -2 (l2) or -1 (ip): this writes that copy ([n_queries][dim_pad] bf16)
+int crag_q16_scale_queries(const void* queries, int n_queries, int dim_pad, int metric, void* out, hipStream_t s);
+#ifndef CRAG_MFMA_SHAPE_DEFAULT
+#define CRAG_MFMA_SHAPE_DEFAULT 32  // which of the two the library takes (crag_capi.hip: mfma_shape)
+#endif
 // bf16 rows too long for a query-stationary form (1536 / 2048 elements) and float32 rows of every length: 128 rows x
 // 32 / 64 / 128 queries per workgroup, both operands through LDS; flat candidate buffers, row-major sample: crag_scan_qlong.hip
 bool crag_qlong_supported(int dtype, int dim_pad);

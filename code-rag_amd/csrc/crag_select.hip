@@ -560,7 +560,9 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
             const double qx = sqrt(qn * X);
             double eps, lb;
             if (a.metric == CRAG_L2) {
-                eps = 2.0 * u * (2.0 * (double)(a.dim_pad + 4) * qx + 3.0 * X + 1e-30);
+                // every partial sum of a scan is bounded by |x|^2 + 2 |q||x|: the 16x16x32 scan starts its accumulators
+                // at |x|^2 (crag_scan_q16.hip); the others add |x|^2 last, which this bound covers as well
+                eps = 2.0 * u * ((double)(a.dim_pad + 4) * (2.0 * qx + X) + 3.0 * X + 1e-30);
                 lb = sM + qn - eps - 1e-12 * (qn + X);
             } else {
                 eps = 2.0 * u * ((double)(a.dim_pad + 4) * qx + 1e-30);
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(256) void k_tau_refine(FinalizeArgs a, float* __res
         const double qx = sqrt(qn * X);
         double t;
         if (a.metric == CRAG_L2) {
-            const double eps = 2.0 * u * (2.0 * (double)(a.dim_pad + 4) * qx + 3.0 * X + 1e-30);
+            const double eps = 2.0 * u * ((double)(a.dim_pad + 4) * (2.0 * qx + X) + 3.0 * X + 1e-30);
             t = (double)d0 - qn + 1.01 * eps + 2e-12 * (qn + X);
         } else {
             const double eps = 2.0 * u * ((double)(a.dim_pad + 4) * qx + 1e-30);

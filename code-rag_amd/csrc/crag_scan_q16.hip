@@ -44,12 +44,8 @@ struct Q16Dma {
     unsigned xn_dst;            // wave-uniform: LDS byte address of this wave's |x|^2 slot
 };
 
-#ifdef Q16_PROFILE  // -DQ16_PROF_REALTIME: the constant 100 MHz counter instead of shader cycles
-#ifdef Q16_PROF_REALTIME
-#define Q16_PROF_NOW() __builtin_amdgcn_s_memrealtime()
-#else
+#ifdef Q16_PROFILE  // diagnostic build only (tools/q16_bench.hip): shader-cycle stamps; the shipped kernel executes none
 #define Q16_PROF_NOW() __builtin_readcyclecounter()
-#endif
 #endif
 #ifndef Q16_KLOOP_INC  // tools/qreg_bench.hip substitutes ablation builds of the statements
 #define Q16_KLOOP_INC "crag_q16_kloop.inc"
@@ -112,9 +108,6 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;  // query column of every 16-query block; row quarter
-#ifdef Q16_PROFILE
-    const unsigned long long prof_entry = Q16_PROF_NOW();
-#endif
 
     // workgroup -> (query group, row-tile stream); workgroups with equal blockIdx % 8 share an XCD
     const int b = blockIdx.x;
@@ -158,9 +151,6 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
                      queries + (long long)(ok[1] ? qn[1] : n_queries - 1) * D + 8 * fg,
                      queries + (long long)(ok[2] ? qn[2] : n_queries - 1) * D + 8 * fg,
                      queries + (long long)(ok[3] ? qn[3] : n_queries - 1) * D + 8 * fg);
-#ifdef Q16_PROFILE
-    const unsigned long long prof_loaded = Q16_PROF_NOW();
-#endif
     float tq[4];
     unsigned pos[4];
     // this workgroup's segments of its queries' candidate buffers (one per row quarter), the lane's private counters
@@ -237,9 +227,10 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     }
     __builtin_amdgcn_s_barrier();
 
-#ifdef Q16_PROFILE  // tools/qreg_bench.hip: time in the end-of-tile wait + barrier vs the whole loop (100 MHz ticks)
-    unsigned long long prof_wait = 0, prof_bar = 0;
-    const unsigned long long prof_t0 = Q16_PROF_NOW();
+#ifdef Q16_PROFILE  // time in the tile statement, the slow path, the end-of-tile wait and the barrier (shader cycles),
+    // and the clock the chip holds: shader cycles per tick of the constant 100 MHz counter over the whole tile loop
+    unsigned long long prof_stmt = 0, prof_slow = 0, prof_wait = 0, prof_bar = 0, prof_tiles = 0;
+    const unsigned long long prof_t0 = Q16_PROF_NOW(), prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (; t < n_tiles; t += t_step) {
         const long long nt2 = t + 2 * t_step;
@@ -251,6 +242,10 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
         // up front otherwise
         const bool dma_in_loop = more && wave_active && (nt2 + 1) * Q16_TM <= row_end;
         if (more && !dma_in_loop) issue(nt2, nxt2);
+#ifdef Q16_PROFILE
+        const unsigned long long prof_s0 = Q16_PROF_NOW();
+        unsigned long long prof_s1 = prof_s0;
+#endif
         if (wave_active) {
             const unsigned a0 = a_lane + cur * STAGE;
             const unsigned xaddr = x_lane + cur * x_step;
@@ -278,6 +273,9 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
             } else {
                 Q16KLoop<KS, false, 0, false>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr);
             }
+#ifdef Q16_PROFILE
+            prof_s1 = Q16_PROF_NOW();
+#endif
             const bool hit0 = mn0 <= tq[0], hit1 = mn1 <= tq[1], hit2 = mn2 <= tq[2], hit3 = mn3 <= tq[3];
             if (MODE == 0 || __any(hit0 || hit1 || hit2 || hit3)) {
                 // row numbers fit 32 bits (rows per collection < 2^32, include/coderag_hip.h)
@@ -356,8 +354,11 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
         __builtin_amdgcn_s_barrier();
 #ifdef Q16_PROFILE
         const unsigned long long prof_c = Q16_PROF_NOW();
+        prof_stmt += prof_s1 - prof_s0;
+        prof_slow += prof_a - prof_s1;
         prof_wait += prof_b - prof_a;
         prof_bar += prof_c - prof_b;
+        ++prof_tiles;
 #endif
         cur = cur + 1 == Q16_NSTAGE ? 0 : cur + 1;
     }
@@ -368,17 +369,16 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     }
     if (prog && wave == 0 && lane == 0) __hip_atomic_store(prog + qg, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef Q16_PROFILE
-    if (lane == 0) {
-        uint32_t* pc = segcnt + Q16_PROFILE;  // tools/qreg_bench.hip: counters behind the segment counters
-        atomicAdd(&pc[0], (unsigned)prof_wait);
-        atomicAdd(&pc[1], (unsigned)prof_bar);
-        atomicAdd(&pc[2], (unsigned)(Q16_PROF_NOW() - prof_t0));
-        atomicAdd(&pc[3], 1u);
-        atomicAdd(&pc[4], (unsigned)(prof_loaded - prof_entry));
-        atomicAdd(&pc[5], (unsigned)(prof_t0 - prof_loaded));
-        atomicMax(&pc[6], ~(unsigned)prof_entry);        // earliest entry (inverted)
-        atomicMax(&pc[7], (unsigned)prof_entry);         // latest entry
-        atomicMax(&pc[8], (unsigned)Q16_PROF_NOW());      // latest exit
+    if (lane == 0) {  // eight 64-bit words per wave behind the segment counters; nothing else reads them
+        unsigned long long* pc = (unsigned long long*)(segcnt + Q16_PROFILE) + ((long long)blockIdx.x * Q16_WAVES + wave) * 8;
+        pc[0] = Q16_PROF_NOW() - prof_t0;
+        pc[1] = __builtin_amdgcn_s_memrealtime() - prof_r0;
+        pc[2] = prof_stmt;
+        pc[3] = prof_slow;
+        pc[4] = prof_wait;
+        pc[5] = prof_bar;
+        pc[6] = prof_tiles;
+        pc[7] = wave_active ? 1 : 0;
     }
 #endif
 }

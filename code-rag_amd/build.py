@@ -35,12 +35,14 @@ def _newer(target, deps):
 _REG = re.compile(r"\b([av])(?:(\d+)\b|\[(\d+):(\d+)\])")
 
 
-def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from):
+def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from, live_vgprs=None):
     """crag_scan_qreg2.hip and crag_scan_qsplit.hip keep their query fragments in fixed registers the compiler
     is not told about (gen_qreg2_kloop.py / gen_qsplit_kloop.py: all AGPRs, and for qreg2 at KS = 48 also
     v[128:255]).  The generated statements list them as clobbers, so nothing of the compiler's lives there
     ACROSS a statement; this check proves on the emitted ISA that no compiler-generated instruction touches
-    them BETWEEN statements either.  hidden_vgpr_from(match) -> first hidden VGPR of that kernel, or None."""
+    them BETWEEN statements either.  hidden_vgpr_from(match) -> first hidden VGPR of that kernel, or None.
+    live_vgprs = (lo, hi): VGPRs that stay live from one statement to the next (crag_scan_q16.hip: the next tile's first
+    LDS reads are in flight into them), so compiler code may not name them either."""
     kernel, in_asm, bad, seen, vlim = None, False, [], set(), None
     for n, line in enumerate(open(asm_path), 1):
         m = re.match(kernel_re, line)
@@ -61,7 +63,9 @@ def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from):
             code = line.split(";")[0]
             for f, one, lo, hi in _REG.findall(code):
                 top = int(one) if one else int(hi)
-                if f == "a" or (vlim is not None and top >= vlim):
+                low = int(one) if one else int(lo)
+                if f == "a" or (vlim is not None and top >= vlim) or \
+                        (f == "v" and live_vgprs is not None and top >= live_vgprs[0] and low <= live_vgprs[1]):
                     bad.append(f"{asm_path}:{n}: {line.strip()}")
     if len(seen) != n_kernels:
         raise RuntimeError(f"check_fixed_register_isa: expected {n_kernels} kernels in {asm_path}, found {len(seen)}")
@@ -76,7 +80,7 @@ def check_qreg2_isa(asm_path):
 
 def check_q16_isa(asm_path):
     check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_q16ILi(\d+)ELi\d+ELb[01]E\S*):", 12,
-                             lambda m: 128 if int(m.group(2)) == 48 else None)
+                             lambda m: 128 if int(m.group(2)) == 48 else None, live_vgprs=(64, 95))
 
 
 def check_qsplit_isa(asm_path):

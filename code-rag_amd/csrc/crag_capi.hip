@@ -657,9 +657,12 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     // zeroed block per level behind the segment counters (MfmaArgs::progress)
     static const int ahead_max = [] {
         const char* e = getenv("CRAG_AHEAD_MAX");  // tuning / A-B runs; 0 switches the pacing off
-        return e ? atoi(e) : 4;
+        const char* v = getenv("CRAG_PACE_EVERY");  // 1, 2, 4, 8 ...: wave 0 publishes and checks every so many tiles
+        int every = v ? atoi(v) : CRAG_PACE_EVERY_DEFAULT;
+        if (every < 1 || every > 128 || (every & (every - 1))) every = CRAG_PACE_EVERY_DEFAULT;
+        return ((e ? atoi(e) : CRAG_AHEAD_MAX_DEFAULT) & 0xff) | ((every - 1) << 8);  // MfmaArgs::ahead_max: tiles | mask << 8
     }();
-    const bool paced = segmented && B > 256 && ahead_max > 0;
+    const bool paced = segmented && B > 256 && (ahead_max & 0xff) > 0;
     const size_t prog_words = paced ? (size_t)CRAG_PROGRESS_WORDS(h0->n_cus) : 0;
     uint32_t* progress = nullptr;
     if (segmented) {

@@ -124,10 +124,13 @@ struct MfmaArgs {
     long long cand_stride;  // slots per query = n_seg * seg_cap (may exceed CRAG_CAND_CAP; the COUNT may not)
     // crag_launch_scan_qreg2 with several query groups (B > 256): pacing words, one 128-byte line per (xcd, stream)
     // pair = CRAG_PROGRESS_WORDS(n_cus) 32-bit words, ZERO at launch (each launch its own); null = no pacing.
-    // ahead_max: tiles a workgroup may run ahead of the slowest one that reads the same tiles.
+    // ahead_max: low byte = tiles a workgroup may run ahead of the slowest one that reads the same tiles; next byte
+    // (crag_scan_q16.hip only) = mask of the tile count at which wave 0 publishes and checks (0: every tile, 3: every fourth)
     uint32_t* progress;
     int ahead_max;
 };
+#define CRAG_AHEAD_MAX_DEFAULT 4
+#define CRAG_PACE_EVERY_DEFAULT 4
 #define CRAG_PROGRESS_WORDS(n_cus) ((long long)((n_cus) / 8 * 8) * 32)
 // query-stationary MFMA scans; their samples are query-minor ([row][stride], or tile-major for qreg2)
 // same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip

@@ -18,6 +18,7 @@
 //   MODE 0 (sample): ordered-float score keys to the TILE-major sample [row / 32][Bpad][row % 32]
 //   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
 #include "crag_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     // polling ONE line with scalar glc loads serialises in its L2 channel: the kernel ran 2.6x longer)
     const unsigned* const pp = prog ? (const unsigned*)prog : (const unsigned*)(queries + (long long)(b % n_queries) * D);
     unsigned tiles_done = 0;
+    const unsigned ahead = (unsigned)ahead_max & 0xffu, pace_mask = ((unsigned)ahead_max >> 8) & 0xffu;  // MfmaArgs::ahead_max
     u32x8_t pv;
 
     const int q_base = qg * Q16_QPB + wave * Q16_QPW;
@@ -225,141 +227,171 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (prog && wave == 0 && lane == 0) {  // pacing line: the slots no query group owns read "finished"
+        for (int i = nqg; i < 8; ++i) __hip_atomic_store(prog + i, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __builtin_amdgcn_s_barrier();
 
 #ifdef Q16_PROFILE  // time in the tile statement, the slow path, the end-of-tile wait and the barrier (shader cycles),
     // and the clock the chip holds: shader cycles per tick of the constant 100 MHz counter over the whole tile loop
-    unsigned long long prof_stmt = 0, prof_slow = 0, prof_wait = 0, prof_bar = 0, prof_tiles = 0;
+    unsigned long long prof_stmt = 0, prof_slow = 0, prof_tiles = 0;
     const unsigned long long prof_t0 = Q16_PROF_NOW(), prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+
+    // what follows a tile statement: the hit test and, rarely, the slow path (appends) or the sample store
+    auto after_tile = [&](const f32x16_t& acc0, const f32x16_t& acc1, float mn0, float mn1, float mn2, float mn3, unsigned tile32) {
+        const bool hit0 = mn0 <= tq[0], hit1 = mn1 <= tq[1], hit2 = mn2 <= tq[2], hit3 = mn3 <= tq[3];
+        if (MODE == 0 || __any(hit0 || hit1 || hit2 || hit3)) {
+            // row numbers fit 32 bits (rows per collection < 2^32, include/coderag_hip.h)
+            const unsigned mb = tile32 * Q16_TM + 4 * fg, re = (unsigned)row_end;
+            if (MODE == 0) {
+                // tile-major sample: key of (row, query) at ((row / 32) * Bpad + query) * 32 + row % 32, so the
+                // lane stores its 4-row runs as 16-byte words and k_kth reads whole 128-byte lines
+                // (rows past row_end land in the tile's padding and are never read)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    uint4* sp = (uint4*)(sample + ((long long)tile32 * sample_stride + qn[jb]) * 32 + 4 * fg);
+                    uint4 k0, k1;
+                    k0.x = crag_fkey(acc0[4 * jb + 0]);
+                    k0.y = crag_fkey(acc0[4 * jb + 1]);
+                    k0.z = crag_fkey(acc0[4 * jb + 2]);
+                    k0.w = crag_fkey(acc0[4 * jb + 3]);
+                    k1.x = crag_fkey(acc1[4 * jb + 0]);
+                    k1.y = crag_fkey(acc1[4 * jb + 1]);
+                    k1.z = crag_fkey(acc1[4 * jb + 2]);
+                    k1.w = crag_fkey(acc1[4 * jb + 3]);
+                    if (ok[jb]) {
+                        sp[0] = k0;  // rows 4 fg + [0,4)
+                        sp[4] = k1;  // rows 16 + 4 fg + [0,4)
+                    }
+                }
+            } else {
+                int qa = qn[0];
+                asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path (not hoisted)
+                unsigned long long* cq = cand + (long long)qa * cand_stride + (long long)seg * seg_cap;
+                if (__any(hit0)) q16_append<0>(acc0, acc1, tq[0], mb, re, cq, (unsigned)seg_cap, pos[0]);
+                if (__any(hit1)) q16_append<1>(acc0, acc1, tq[1], mb, re, cq + 16ll * cand_stride, (unsigned)seg_cap, pos[1]);
+                if (__any(hit2)) q16_append<2>(acc0, acc1, tq[2], mb, re, cq + 32ll * cand_stride, (unsigned)seg_cap, pos[2]);
+                if (__any(hit3)) q16_append<3>(acc0, acc1, tq[3], mb, re, cq + 48ll * cand_stride, (unsigned)seg_cap, pos[3]);
+                // vmcnt counts these stores too (and they may retire out of order with the DMA loads), but the
+                // counter is never below the number of outstanding loads and loads retire in order, so the counted
+                // wait at the end of the next tile still proves that its successor has landed; it only waits a little longer
+            }
+        }
+    };
+
+    // ---- steady state of a filter launch (the waves that hold queries): Q16Fast statements, one per tile --------
+    // Runs while the tile two steps ahead exists and is whole (its DMA rides between the MFMAs).  Per tile the wave
+    // executes: [wave 0: pacing], one statement (which ends with the counted vmcnt wait, the barrier and the first reads
+    // of the next tile), the hit test, and a dozen scalar instructions of bookkeeping -- every instruction outside the
+    // MFMA stream costs this wave (one per SIMD) four cycles, so the general loop's 64-bit index arithmetic is kept out.
+    long long n_fast = 0;
+    if (MODE == 1 && wave_active) {
+        const long long last_whole = row_end / Q16_TM - 1;
+        if (t + 2 * t_step <= last_whole) n_fast = (last_whole - t - 2 * t_step) / t_step + 1;
+    }
+    if (n_fast > 0) {
+        auto fast = [&](auto ph) {
+            constexpr int PH = decltype(ph)::value;
+            Q16First<KS>::run(a_lane + cur * STAGE, x_lane + cur * x_step);
+            Q16Dma<PPW> d;
+#pragma unroll
+            for (int i = 0; i < HP; ++i) d.voff[i] = voff[i];
+            d.tile = (const unsigned char*)rows + (t + 2 * t_step) * (long long)STAGE;
+            d.xoff = lane * 4;
+            d.xn = xnorm + (t + 2 * t_step) * Q16_TM;
+            const long long tile_inc = t_step * (long long)STAGE;
+            const long long xn_inc = t_step * Q16_TM;
+            unsigned tile32 = (unsigned)t;
+            const unsigned step32 = (unsigned)t_step;
+            unsigned left = (unsigned)n_fast;  // < 2^27 tiles
+            int nxt = cur + 1 == Q16_NSTAGE ? 0 : cur + 1;
+            do {
+                const int nxt2 = nxt + 1 == Q16_NSTAGE ? 0 : nxt + 1;
+                if constexpr (PH == 0 && !NT) {
+                    // wave 0 of a workgroup that shares its tiles, every (pace_mask + 1)-th tile: publish the tile count, then
+                    // wait for the slowest partner.  (Every tile cost the whole workgroup ~80 cycles per tile behind wave 0:
+                    // the other waves meet it at the statement's barrier.)
+                    if (pacing && (tiles_done & pace_mask) == 0) {
+                        if (lane == 0) __hip_atomic_store(prog + qg, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (tiles_done) {  // the previous statement polled the partners (their counts as of its start)
+                            for (int spin = 0;; ++spin) {
+                                unsigned slowest = pv[0];
+#pragma unroll
+                                for (int i = 1; i < 8; ++i) slowest = pv[i] < slowest ? pv[i] : slowest;
+                                if (tiles_done <= slowest + ahead) break;
+                                if (spin == 96) {  // ~150 us: the partner is not on the chip; stop pacing for good
+                                    pacing = false;
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(16);
+                                asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pv) : "s"(pp) : "memory");
+                            }
+                        }
+                    }
+                    ++tiles_done;
+                }
+                d.tile_hi = d.tile + HALF;
+                d.lds_dst = lds_base + nxt2 * STAGE + wave * 1024;
+                d.xn_dst = lds_base + XN_BASE + (nxt2 * Q16_WAVES + wave) * Q16_XN_BYTES;
+                f32x16_t acc0, acc1;  // row block rb: element 4 jb + e = SCORE of row 16 rb + 4 fg + e against the query of block jb
+                float mn0, mn1, mn2, mn3;
+#ifdef Q16_PROFILE
+                const unsigned long long prof_s0 = Q16_PROF_NOW();
+#endif
+                if constexpr (PH == 0 && !NT)
+                    Q16Fast<KS, 0, false>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + nxt * STAGE, x_lane + nxt * x_step, d, pp, pv);
+                else
+                    Q16Fast<KS, PH, NT>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + nxt * STAGE, x_lane + nxt * x_step, d);
+#ifdef Q16_PROFILE
+                const unsigned long long prof_s1 = Q16_PROF_NOW();
+#endif
+                after_tile(acc0, acc1, mn0, mn1, mn2, mn3, tile32);
+#ifdef Q16_PROFILE
+                prof_stmt += prof_s1 - prof_s0;
+                prof_slow += Q16_PROF_NOW() - prof_s1;
+                ++prof_tiles;
+#endif
+                cur = nxt;
+                nxt = nxt2;
+                d.tile += tile_inc;
+                d.xn += xn_inc;
+                tile32 += step32;
+            } while (--left);
+        };
+        switch (wave) {  // the DMA slots of the statement are staggered by wave
+            case 0: fast(std::integral_constant<int, 0>{}); break;
+            case 1: fast(std::integral_constant<int, 1>{}); break;
+            case 2: fast(std::integral_constant<int, 2>{}); break;
+            default: fast(std::integral_constant<int, 3>{}); break;
+        }
+        t += n_fast * t_step;
+    }
+
+    // ---- general path: sample launches, the last tiles of a stream, ragged tiles, waves without queries -----------
+    // (a wave without queries runs ALL its tiles here: DMA up front, wait, barrier -- one barrier per tile, as the
+    // statements of the other waves execute)
     for (; t < n_tiles; t += t_step) {
         const long long nt2 = t + 2 * t_step;
         const bool more = nt2 < n_tiles;  // workgroup-uniform
         int nxt2 = cur + 2;
         if (nxt2 >= Q16_NSTAGE) nxt2 -= Q16_NSTAGE;
-        // prefetch tile t + 2 steps into the buffer of tile t - step (every wave left it before the last
-        // barrier): between the MFMAs of the K-loop when this wave multiplies and the tile is whole,
-        // up front otherwise
-        const bool dma_in_loop = more && wave_active && (nt2 + 1) * Q16_TM <= row_end;
-        if (more && !dma_in_loop) issue(nt2, nxt2);
-#ifdef Q16_PROFILE
-        const unsigned long long prof_s0 = Q16_PROF_NOW();
-        unsigned long long prof_s1 = prof_s0;
-#endif
+        // prefetch tile t + 2 steps into the buffer of tile t - step (every wave left it before the last barrier)
+        if (more) issue(nt2, nxt2);
         if (wave_active) {
-            const unsigned a0 = a_lane + cur * STAGE;
-            const unsigned xaddr = x_lane + cur * x_step;
-            f32x16_t acc0, acc1;  // row block rb: element 4 jb + e = SCORE of row 16 rb + 4 fg + e against the query of block jb
+            f32x16_t acc0, acc1;
             float mn0, mn1, mn2, mn3;
-            if (dma_in_loop) {
-                Q16Dma<PPW> d;
-#pragma unroll
-                for (int i = 0; i < HP; ++i) d.voff[i] = voff[i];
-                d.tile = (const unsigned char*)rows + nt2 * (long long)STAGE;
-                d.tile_hi = d.tile + HALF;
-                d.lds_dst = lds_base + nxt2 * STAGE + wave * 1024;
-                d.xoff = lane * 4;
-                d.xn = xnorm + nt2 * Q16_TM;
-                d.xn_dst = lds_base + XN_BASE + (nxt2 * Q16_WAVES + wave) * Q16_XN_BYTES;
-                switch (wave) {  // the DMA slots of the K-loop are staggered by wave
-                    case 0:
-                        if constexpr (NT) Q16KLoop<KS, true, 0, true>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr, d);
-                        else Q16KLoop<KS, true, 0, false>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr, d, pp, pv);
-                        break;
-                    case 1: Q16KLoop<KS, true, 1, NT>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr, d); break;
-                    case 2: Q16KLoop<KS, true, 2, NT>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr, d); break;
-                    default: Q16KLoop<KS, true, 3, NT>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr, d); break;
-                }
-            } else {
-                Q16KLoop<KS, false, 0, false>::run(acc0, acc1, mn0, mn1, mn2, mn3, a0, xaddr);
-            }
-#ifdef Q16_PROFILE
-            prof_s1 = Q16_PROF_NOW();
-#endif
-            const bool hit0 = mn0 <= tq[0], hit1 = mn1 <= tq[1], hit2 = mn2 <= tq[2], hit3 = mn3 <= tq[3];
-            if (MODE == 0 || __any(hit0 || hit1 || hit2 || hit3)) {
-                // row numbers fit 32 bits (rows per collection < 2^32, include/coderag_hip.h)
-                const unsigned mb = (unsigned)t * Q16_TM + 4 * fg, re = (unsigned)row_end;
-                if (MODE == 0) {
-                    // tile-major sample: key of (row, query) at ((row / 32) * Bpad + query) * 32 + row % 32, so the
-                    // lane stores its 4-row runs as 16-byte words and k_kth reads whole 128-byte lines
-                    // (rows past row_end land in the tile's padding and are never read)
-#pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) {
-                        uint4* sp = (uint4*)(sample + ((long long)t * sample_stride + qn[jb]) * 32 + 4 * fg);
-                        uint4 k0, k1;
-                        k0.x = crag_fkey(acc0[4 * jb + 0]);
-                        k0.y = crag_fkey(acc0[4 * jb + 1]);
-                        k0.z = crag_fkey(acc0[4 * jb + 2]);
-                        k0.w = crag_fkey(acc0[4 * jb + 3]);
-                        k1.x = crag_fkey(acc1[4 * jb + 0]);
-                        k1.y = crag_fkey(acc1[4 * jb + 1]);
-                        k1.z = crag_fkey(acc1[4 * jb + 2]);
-                        k1.w = crag_fkey(acc1[4 * jb + 3]);
-                        if (ok[jb]) {
-                            sp[0] = k0;  // rows 4 fg + [0,4)
-                            sp[4] = k1;  // rows 16 + 4 fg + [0,4)
-                        }
-                    }
-                } else {
-                    {
-                        int qa = qn[0];
-                        asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path (not hoisted)
-                        unsigned long long* cq = cand + (long long)qa * cand_stride + (long long)seg * seg_cap;
-                        if (__any(hit0)) q16_append<0>(acc0, acc1, tq[0], mb, re, cq, (unsigned)seg_cap, pos[0]);
-                        if (__any(hit1)) q16_append<1>(acc0, acc1, tq[1], mb, re, cq + 16ll * cand_stride, (unsigned)seg_cap, pos[1]);
-                        if (__any(hit2)) q16_append<2>(acc0, acc1, tq[2], mb, re, cq + 32ll * cand_stride, (unsigned)seg_cap, pos[2]);
-                        if (__any(hit3)) q16_append<3>(acc0, acc1, tq[3], mb, re, cq + 48ll * cand_stride, (unsigned)seg_cap, pos[3]);
-                    }
-                    // vmcnt counts these stores too (and they may retire out of order with the DMA loads), but the
-                    // counter is never below the number of outstanding loads and loads retire in order, so the
-                    // counted wait below still proves that the next tile has landed; it only waits a little longer
-                }
-            }
+            Q16KLoop<KS>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + cur * STAGE, x_lane + cur * x_step);
+            after_tile(acc0, acc1, mn0, mn1, mn2, mn3, (unsigned)t);
         }
         // tile t + step must have landed in every wave's view before anyone reads it: each wave retires all
         // but the DMA instructions it issued in THIS iteration (they are its youngest), then the barrier
-#ifdef Q16_PROFILE
-        const unsigned long long prof_a = Q16_PROF_NOW();
-#endif
         if (more) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if constexpr (MODE == 1 && !NT) {
-            if (pacing) {  // wave 0 of a workgroup that shares its tiles
-                ++tiles_done;
-                if (lane == 0) __hip_atomic_store(prog + qg, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dma_in_loop) {  // this tile's statement polled the partners (their counts as of its start)
-                    for (int spin = 0;; ++spin) {
-                        unsigned slowest = 0xffffffffu;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            if (i < nqg && i != qg) slowest = pv[i] < slowest ? pv[i] : slowest;
-                        if (tiles_done <= slowest + (unsigned)ahead_max) break;
-                        if (spin == 96) {  // ~150 us: the partner is not on the chip; stop pacing for good
-                            pacing = false;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(16);
-                        asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pv) : "s"(pp) : "memory");
-                    }
-                }
-            }
-        }
-#ifdef Q16_PROFILE
-        const unsigned long long prof_b = Q16_PROF_NOW();
-#endif
         __builtin_amdgcn_s_barrier();
-#ifdef Q16_PROFILE
-        const unsigned long long prof_c = Q16_PROF_NOW();
-        prof_stmt += prof_s1 - prof_s0;
-        prof_slow += prof_a - prof_s1;
-        prof_wait += prof_b - prof_a;
-        prof_bar += prof_c - prof_b;
-        ++prof_tiles;
-#endif
         cur = cur + 1 == Q16_NSTAGE ? 0 : cur + 1;
     }
     if (MODE == 1 && wave_active) {
@@ -375,8 +407,8 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
         pc[1] = __builtin_amdgcn_s_memrealtime() - prof_r0;
         pc[2] = prof_stmt;
         pc[3] = prof_slow;
-        pc[4] = prof_wait;
-        pc[5] = prof_bar;
+        pc[4] = 0;
+        pc[5] = 0;
         pc[6] = prof_tiles;
         pc[7] = wave_active ? 1 : 0;
     }

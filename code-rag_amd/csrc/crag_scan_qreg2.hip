@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * Q2_WAVES, 1) void k_scan_qreg2(const unsigned 
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
                             if (i < nqg && i != qg) slowest = pv[i] < slowest ? pv[i] : slowest;
-                        if (tiles_done <= slowest + (unsigned)ahead_max) break;
+                        if (tiles_done <= slowest + ((unsigned)ahead_max & 0xffu)) break;
                         if (spin == 96) {  // ~150 us: the partner is not on the chip; stop pacing for good
                             pacing = false;
                             break;

@@ -59,7 +59,7 @@ def scan_kernel_name(d, B, path, n=10_000_000, top_k=10):
         return "k_scan_qsplit"
     m = 2 * top_k + max(16, 2 * top_k // 8)
     first = (1 if n >= 4_000_000 else 2) if d >= 768 else (3 if d >= 512 or m > 64 else 5)
-    return "k_scan_qreg2" if (B >= first or path == "mfma") else "k_scan_gemv"
+    return "k_scan_q16" if (B >= first or path == "mfma") else "k_scan_gemv"
 
 
 def kernel_sources_sha():

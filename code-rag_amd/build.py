@@ -16,12 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libcoderag_hip.so")
-SOURCES = ["crag_scan_gemv.hip", "crag_scan_qreg2.hip", "crag_scan_q16.hip", "crag_scan_qsplit.hip", "crag_scan_qlong.hip",
+SOURCES = ["crag_scan_gemv.hip", "crag_scan_q16.hip", "crag_scan_qsplit.hip", "crag_scan_qlong.hip",
            "crag_select.hip", "crag_capi.hip"]
-INCLUDES = {"crag_scan_qreg2.hip": ["crag_qreg2_kloop.inc"],
-            "crag_scan_q16.hip": ["crag_q16_kloop.inc"],
+INCLUDES = {"crag_scan_q16.hip": ["crag_q16_kloop.inc"],
             "crag_scan_qsplit.hip": ["crag_qsplit_kloop.inc"]}
-ISA_CHECKED = ("crag_scan_qreg2.hip", "crag_scan_q16.hip", "crag_scan_qsplit.hip", "crag_scan_gemv.hip", "crag_scan_qlong.hip")
+ISA_CHECKED = ("crag_scan_q16.hip", "crag_scan_qsplit.hip", "crag_scan_gemv.hip", "crag_scan_qlong.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -71,11 +70,6 @@ def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from, l
         raise RuntimeError(f"check_fixed_register_isa: expected {n_kernels} kernels in {asm_path}, found {len(seen)}")
     if bad:
         raise RuntimeError("check_fixed_register_isa: compiler code touches the fixed fragment registers:\n" + "\n".join(bad[:20]))
-
-
-def check_qreg2_isa(asm_path):
-    check_fixed_register_isa(asm_path, r"^(_Z\S*k_scan_qreg2ILi(\d+)ELi\d+ELb[01]E\S*):", 12,
-                             lambda m: 128 if int(m.group(2)) == 48 else None)
 
 
 def check_q16_isa(asm_path):
@@ -174,7 +168,6 @@ def build(force=False, verbose=True):
         deps = [src] + headers + [os.path.join(SRC, i) for i in INCLUDES.get(s, [])]
         if not os.path.exists(asm) or any(os.path.getmtime(d) > os.path.getmtime(asm) for d in deps):
             raise RuntimeError(f"{asm} is missing or older than its sources: the fixed-register check would vouch for other code than {obj}")
-    check_qreg2_isa(os.path.join(OBJ, "crag_scan_qreg2.s"))
     check_q16_isa(os.path.join(OBJ, "crag_scan_q16.s"))
     check_qsplit_isa(os.path.join(OBJ, "crag_scan_qsplit.s"))
     check_gemv_isa(os.path.join(OBJ, "crag_scan_gemv.s"))

@@ -278,7 +278,7 @@ class GpuCollection:
         out = torch.empty((queries.shape[0], len(self)), dtype=torch.float32, device=queries.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self._lib.crag_debug_dense_scores(self._h, queries.data_ptr(), queries.shape[0],
-                                                {"gemv": 1, "mfma": 2, "tiled": 3, "mfma16": 2, "mfma32": 2}[path], out.data_ptr(), st),
+                                                {"gemv": 1, "mfma": 2, "tiled": 3}[path], out.data_ptr(), st),
               "crag_debug_dense_scores")
         return out
 
@@ -292,7 +292,7 @@ class GpuCollection:
                 "filter_scan_rows": float(a[3])}
 
     def set_path(self, path: str):
-        check(self._lib.crag_set_path(self._h, {"auto": 0, "gemv": 1, "mfma": 2, "tiled": 3, "mfma16": 4, "mfma32": 5}[path]))
+        check(self._lib.crag_set_path(self._h, {"auto": 0, "gemv": 1, "mfma": 2, "tiled": 3}[path]))
 
 
 def merge_rerank_device(device: int, entries, n_shards: int, b: int, top_k: int, symbol_boost: float, out=None,

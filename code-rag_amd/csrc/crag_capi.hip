@@ -258,7 +258,6 @@ struct crag_index {
     std::vector<uint8_t> len_present;  // index = byte length
     int max_name_len = 0;
     int force_path = 0;
-    int force_shape = 0;  // 16 / 32: matrix shape of the query-stationary scan for this handle (crag_set_path 4 / 5), 0 = library default
     int n_cus = 256;
     int profiling = 0;
     std::mutex prof_mu;
@@ -356,24 +355,6 @@ long long level1_rows(long long N, long long n0, int M, double direct_max) {
 // (tools/sweep_tunables.sh history in DESIGN.md): at top-10 (M = 36) r between 3 and 6 is flat within 0.5 %, so
 // r ~ 6 (fewest launches), and up to r = 20 it stays within 0.5 % (round 2: a level saved is paid back by the
 // longer last level and its looser threshold); at top-100 (M = 225) r ~ 3 is 1.5-2 % ahead of r ~ 6 and of r ~ 2.
-// which bf16 matrix shape the query-stationary scan of rows up to 768 elements runs in: 16 = v_mfma_f32_16x16x32_bf16
-// (crag_scan_q16.hip), 32 = v_mfma_f32_32x32x16_bf16 (crag_scan_qreg2.hip).  CRAG_MFMA_SHAPE overrides it for A/B runs
-// (read once per process).
-int mfma_shape() {
-    static const int shape = [] {
-        const char* e = getenv("CRAG_MFMA_SHAPE");
-        const int v = e ? atoi(e) : 0;
-        return v == 16 || v == 32 ? v : CRAG_MFMA_SHAPE_DEFAULT;
-    }();
-    return shape;
-}
-// (the selection kernels gather at most 1024 segments per query: 4 x 8 x 32 streams on the 256 CUs of an MI355X)
-bool use_q16(const crag_index* h) { return (h->force_shape ? h->force_shape : mfma_shape()) == 16 && h->n_cus <= 256; }
-int qstat_segments(const crag_index* h, int B) { return use_q16(h) ? crag_q16_segments(B, h->n_cus) : crag_qreg2_segments(B, h->n_cus); }
-int launch_scan_qstat(const crag_index* h, const MfmaArgs& a, int mode, hipStream_t s) {
-    return use_q16(h) ? crag_launch_scan_q16(a, mode, h->n_cus, s) : crag_launch_scan_qreg2(a, mode, h->n_cus, s);
-}
-
 constexpr int CRAG_MAX_LEVELS = 8;
 typedef SmallVec<long long, CRAG_MAX_LEVELS> LevelBounds;
 LevelBounds cascade_bounds(long long N, long long n0, int M) {
@@ -521,7 +502,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     if (P.M > CRAG_MAX_M) P.M = CRAG_MAX_M;
 
     // ---- which scan: GEMV groups of up to 8 queries, or one of the MFMA scans (one collection per call only) ----
-    //   bf16 up to 768 elements   two-block query-stationary cascade (crag_scan_qreg2.hip)
+    //   bf16 up to 768 elements   query-stationary cascade (crag_scan_q16.hip)
     //   bf16 1024 elements        split-K query-stationary scan (crag_scan_qsplit.hip)
     //   bf16 1536 / 2048, float32 LDS-tiled scan (crag_scan_qlong.hip); a hand-scheduled query-stationary float32 scan
     //                             served rows up to 384 elements until round 2 -- the tiled scan in plain HIP was 3-10 %
@@ -539,7 +520,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     //              VALU-bound (6-8 queries 0.90-1.0 / 0.75)
     const int path = h0->force_path;  // 0 auto, 1 GEMV, 2 MFMA, 3 tiled MFMA (tests, bench, tools)
     const bool bf16 = h0->dtype == CRAG_BF16;
-    const bool can_qreg = bf16 && crag_qreg2_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
+    const bool can_qreg = bf16 && crag_q16_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
     const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad);
     int mfma_from;
     if (can_qsplit) mfma_from = 1;
@@ -645,10 +626,9 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     unsigned long long* cand = nullptr;
     // no memset of the counters: level 0's selection (k_kth) writes every query's counter -- flat or per segment --
     // when it seeds the buffers, and k_finalize writes every query's status
-    const int n_seg = segmented ? qstat_segments(h0, B) : 0;
-    // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 64; >= 32 in the 16x16x32 shape, which has
-    // twice the segments): the COUNT must stay <= CAP
-    const int seg_cap = segmented ? std::max(use_q16(h0) ? 32 : 64, 2 * CRAG_CAND_CAP / n_seg) : 0;
+    const int n_seg = segmented ? crag_q16_segments(B, h0->n_cus) : 0;
+    // physical room for twice CRAG_CAND_CAP per query (a segment holds >= 32): the COUNT must stay <= CAP
+    const int seg_cap = segmented ? std::max(32, 2 * CRAG_CAND_CAP / n_seg) : 0;
     const long long cand_stride = segmented ? (long long)n_seg * seg_cap : (long long)CRAG_CAND_CAP;
     if ((rc = ws->cand.ensure(sizeof(unsigned long long) * (size_t)B * (size_t)cand_stride))) return rc;
     cand = (unsigned long long*)ws->cand.p;
@@ -684,7 +664,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         ma.xnorm = h0->xnorm;
         ma.n_rows = h0->n_rows;
         ma.queries = q_dev;
-        if (segmented && use_q16(h0)) {  // its accumulators are the scores: B operand = -2 q (l2) / -q (ip), once per search
+        if (segmented) {  // its accumulators are the scores: B operand = -2 q (l2) / -q (ip), once per search
             if ((rc = ws->qscan.ensure((size_t)B * h0->dim_pad * 2))) return rc;
             if (crag_q16_scale_queries(q_dev, B, h0->dim_pad, h0->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
             ma.queries = ws->qscan.p;
@@ -727,7 +707,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     double prof_rows = 0.0;  // rows the last (timed) filter launch scans
     if (cascade) {
         auto launch_level = [&](int mode) -> int {
-            if (segmented) return launch_scan_qstat(h0, ma, mode, st);
+            if (segmented) return crag_launch_scan_q16(ma, mode, h0->n_cus, st);
             if (qsplit) return crag_launch_scan_qsplit(ma, mode, h0->n_cus, st);
             return crag_launch_scan_qlong(ma, h0->dtype, mode, h0->n_cus, st);
         };
@@ -951,7 +931,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
                 ma.row_begin = 0;
                 ma.row_end = h0->n_rows;
                 ma.progress = nullptr;
-                if (segmented ? launch_scan_qstat(h0, ma, 1, st)
+                if (segmented ? crag_launch_scan_q16(ma, 1, h0->n_cus, st)
                     : qsplit  ? crag_launch_scan_qsplit(ma, 1, h0->n_cus, st)
                               : crag_launch_scan_qlong(ma, h0->dtype, 1, h0->n_cus, st))
                     return fail(CRAG_E_HIP, "re-scan launch failed");
@@ -1624,13 +1604,13 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = stride;
         const bool d_qsplit = d_bf16 && crag_qsplit_supported(h->dim_pad);
-        const bool d_qreg2 = d_bf16 && crag_qreg2_supported(h->dim_pad);
+        const bool d_qreg2 = d_bf16 && crag_q16_supported(h->dim_pad);
         const bool d_qlong = crag_qlong_supported(h->dtype, h->dim_pad);
         if (!d_qsplit && !d_qreg2 && !d_qlong) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
         rowmajor = true;
         bpad = ((long long)B + 15) / 16 * 16;
-        tiled = d_qreg2;  // crag_launch_scan_qreg2's tile-major sample
-        if (d_qreg2 && use_q16(h)) {
+        tiled = d_qreg2;  // crag_launch_scan_q16's tile-major sample
+        if (d_qreg2) {
             if ((rc = ws->qscan.ensure((size_t)B * h->dim_pad * 2))) return rc;
             if (crag_q16_scale_queries(q, B, h->dim_pad, h->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
             a.queries = ws->qscan.p;
@@ -1640,7 +1620,7 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.sample_stride = bpad;
         if (d_qsplit   ? crag_launch_scan_qsplit(a, 0, h->n_cus, st)
             : d_qlong  ? crag_launch_scan_qlong(a, h->dtype, 0, h->n_cus, st)
-                       : launch_scan_qstat(h, a, 0, st))
+                       : crag_launch_scan_q16(a, 0, h->n_cus, st))
             return fail(CRAG_E_HIP, "mfma scan launch failed");
     } else {
         std::vector<GroupDesc> gd;
@@ -1706,9 +1686,8 @@ int crag_get_profile(crag_index* h, double* out4, int reset) {
 }
 
 int crag_set_path(crag_index* h, int path) {
-    if (!h || path < 0 || path > 5) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
-    h->force_path = path >= 4 ? 2 : path;                 // 4 / 5: the MFMA scans, with the query-stationary one in the
-    h->force_shape = path == 4 ? 16 : path == 5 ? 32 : 0;  // 16x16x32 / 32x32x16 matrix shape (A/B runs, tests)
+    if (!h || path < 0 || path > 3) return fail(CRAG_E_INVALID, "crag_set_path: bad arguments");
+    h->force_path = path;
     return 0;
 }
 

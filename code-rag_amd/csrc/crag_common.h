@@ -116,40 +116,34 @@ struct MfmaArgs {
     long long sample_stride;
     unsigned long long* cand;
     uint32_t* cnt;
-    // crag_launch_scan_qreg2 only: SEGMENTED candidate buffers.  A query's cand_stride slots are cut into
-    // n_seg segments of seg_cap, two per workgroup that scans for the query; a lane appends to its own segment
+    // crag_launch_scan_q16 only: SEGMENTED candidate buffers.  A query's cand_stride slots are cut into
+    // n_seg segments of seg_cap, four per workgroup that scans for the query; a lane appends to its own segment
     // with a private counter (segcnt[q * n_seg + seg], loaded at kernel start, stored at its end): no atomics.
     uint32_t* segcnt;
     int n_seg, seg_cap;
     long long cand_stride;  // slots per query = n_seg * seg_cap (may exceed CRAG_CAND_CAP; the COUNT may not)
-    // crag_launch_scan_qreg2 with several query groups (B > 256): pacing words, one 128-byte line per (xcd, stream)
+    // crag_launch_scan_q16 with several query groups (B > 256): pacing words, one 128-byte line per (xcd, stream)
     // pair = CRAG_PROGRESS_WORDS(n_cus) 32-bit words, ZERO at launch (each launch its own); null = no pacing.
     // ahead_max: low byte = tiles a workgroup may run ahead of the slowest one that reads the same tiles; next byte
-    // (crag_scan_q16.hip only) = mask of the tile count at which wave 0 publishes and checks (0: every tile, 3: every fourth)
+    // = mask of the tile count at which wave 0 publishes and checks (0: every tile, 7: every eighth)
     uint32_t* progress;
     int ahead_max;
 };
-#define CRAG_AHEAD_MAX_DEFAULT 4
-#define CRAG_PACE_EVERY_DEFAULT 4
+#define CRAG_AHEAD_MAX_DEFAULT 8
+#define CRAG_PACE_EVERY_DEFAULT 8
 #define CRAG_PROGRESS_WORDS(n_cus) ((long long)((n_cus) / 8 * 8) * 32)
-// query-stationary MFMA scans; their samples are query-minor ([row][stride], or tile-major for qreg2)
+// query-stationary MFMA scans; their samples are query-minor ([row][stride], or tile-major for crag_scan_q16.hip)
 // same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip
 bool crag_qsplit_supported(int dim_pad);
 int crag_launch_scan_qsplit(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
-// bf16 rows of 256 / 384 / 512 / 768 elements, 256 queries per workgroup (two 32-query blocks per wave), segmented
-// candidate buffers, tile-major sample: crag_scan_qreg2.hip
-bool crag_qreg2_supported(int dim_pad);
-int crag_launch_scan_qreg2(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
-// segments per query that crag_launch_scan_qreg2 will use for this batch size (MfmaArgs::n_seg)
-int crag_qreg2_segments(int n_queries, int n_cus);
-// the same scan in the v_mfma_f32_16x16x32_bf16 shape (crag_scan_q16.hip): same contract, FOUR segments per workgroup
+// bf16 rows of 256 / 384 / 512 / 768 elements, 256 queries per workgroup (four 16-query blocks per wave,
+// v_mfma_f32_16x16x32_bf16), segmented candidate buffers (four segments per workgroup), tile-major sample: crag_scan_q16.hip
+bool crag_q16_supported(int dim_pad);
 int crag_launch_scan_q16(const MfmaArgs& a, int mode, int n_cus, hipStream_t s);
+// segments per query that crag_launch_scan_q16 will use for this batch size (MfmaArgs::n_seg)
 int crag_q16_segments(int n_queries, int n_cus);
-// ... whose MfmaArgs::queries are the caller's queries scaled by -2 (l2) or -1 (ip): this writes that copy ([n_queries][dim_pad] bf16)
+// its MfmaArgs::queries are the caller's queries scaled by -2 (l2) or -1 (ip): this writes that copy ([n_queries][dim_pad] bf16)
 int crag_q16_scale_queries(const void* queries, int n_queries, int dim_pad, int metric, void* out, hipStream_t s);
-#ifndef CRAG_MFMA_SHAPE_DEFAULT
-#define CRAG_MFMA_SHAPE_DEFAULT 32  // which of the two the library takes (crag_capi.hip: mfma_shape)
-#endif
 // bf16 rows too long for a query-stationary form (1536 / 2048 elements) and float32 rows of every length: 128 rows x
 // 32 / 64 / 128 queries per workgroup, both operands through LDS; flat candidate buffers, row-major sample: crag_scan_qlong.hip
 bool crag_qlong_supported(int dtype, int dim_pad);
@@ -181,7 +175,7 @@ struct KthArgs {
     // seed_cnt is the segment counter array -- the scan workgroups then append behind the seeds
     int seed_n_seg, seed_seg_cap;
     long long seed_stride;
-    // > 0: src is the tile-major sample of crag_launch_scan_qreg2 with this Bpad (q_stride, e_stride, off0 unused)
+    // > 0: src is the tile-major sample of crag_launch_scan_q16 with this Bpad (q_stride, e_stride, off0 unused)
     long long tile_bpad;
 };
 int crag_launch_kth(const KthArgs& a, hipStream_t s);

@@ -1,19 +1,24 @@
-// K2 (query-stationary form, v_mfma_f32_16x16x32_bf16): MFMA scan for query batches of any size, bf16,
+// K2 (query-stationary form): MFMA scan for query batches of any size (from 1-5 queries up on the auto path), bf16,
 // dim_pad <= 768, gfx950.
 //
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
 //
-// The dataflow of crag_scan_qreg2.hip (queries never move: 64 per wave, 256 per workgroup, held in fixed registers as
-// the MFMA B operand; 32-row corpus tiles stream HBM -> LDS by LDS-DMA through a ring of three buffers; one wave per
-// SIMD; fused threshold filter; segmented, atomic-free candidate buffers; pacing between the workgroups that share a
-// tile stream) in the OTHER bf16 matrix shape: the wave's 32 x 64 output tile is 2 row blocks x 4 query blocks of
-// 16x16 accumulators instead of 2 query blocks of 32x32.  Same LDS image, LDS reads, DMA, registers and flops per
-// tile.  Why: the scan is power-bound at large batches, and the chip holds a higher clock on the
-// 16x16x32 shape (MI355X_MICROARCH.md, "DVFS give-back" item 7; cdna_hip_programming.md section 5.4 rule 28).
+// Query-stationary dataflow: queries never move -- 64 per wave, 256 per workgroup, held in fixed registers (all 256
+// AGPRs + v[128:255] at D = 768) as the MFMA B operand for every k-step; 32-row corpus tiles stream HBM -> LDS by
+// LDS-DMA through a ring of three buffers (source-side XOR swizzle, conflict-free ds_read_b128); one wave per SIMD
+// (512 registers); fused threshold filter with the query on the lane; segmented, atomic-free candidate buffers;
+// pacing between the workgroups that share a tile stream.  Matrix shape v_mfma_f32_16x16x32_bf16: the wave's 32 x 64
+// output tile is 2 row blocks x 4 query blocks of 16x16 accumulators.  Round 3 measured it against the 32x32x16 form
+// of rounds 1-2 (same tile, LDS image, DMA, registers, flops; profiles/r03_ab_shapes_*.jsonl; git d9d5712 holds both kernels and tools/ab_shapes.py): the
+// scan is power-bound at large batches and the chip holds a higher clock on this shape (MI355X_MICROARCH.md, "DVFS
+// give-back" item 7; cdna_hip_programming.md section 5.4 rule 28): +5 % with the epilogue unchanged, +11-15 % with the
+// score accumulated in place (below), never slower at any batch size or row length -- the 32x32x16 kernel was deleted.
 // A query sits on the four lanes fr, fr + 16, fr + 32, fr + 48 (eight rows of the tile each), so a workgroup appends to
-// FOUR segments of a query's candidate buffer.  The tile statement is generated: crag_q16_kloop.inc (gen_q16_kloop.py
-// holds the register contract, build.py checks it on the emitted ISA).
+// FOUR segments of a query's candidate buffer.  The accumulators ARE the scores: the B operand is the query scaled by
+// -2 (l2) / -1 (ip) and the first MFMA of a tile takes C = |x|^2 (k_q16_scale_queries, gen_q16_kloop.py).  The tile
+// statements are generated: crag_q16_kloop.inc (gen_q16_kloop.py holds the register contract, build.py checks it on
+// the emitted ISA).
 //
 //   MODE 0 (sample): ordered-float score keys to the TILE-major sample [row / 32][Bpad][row % 32]
 //   MODE 1 (filter): s <= tau -> append (score key << 32 | row) to the query's candidate buffer
@@ -445,7 +450,12 @@ int launch_ks(const MfmaArgs& a, int mode, int grid, int nqg, hipStream_t s) {
 
 }  // namespace
 
+bool crag_q16_supported(int dim_pad) { return dim_pad == 256 || dim_pad == 384 || dim_pad == 512 || dim_pad == 768; }
+
+// (the selection kernels gather at most 1024 segments per query -- 4 x 8 x 32 streams on the 256 CUs of an MI355X --
+// so a larger device is used as 256 CUs)
 int crag_q16_segments(int n_queries, int n_cus) {
+    n_cus = n_cus > 256 ? 256 : n_cus;
     const int nqg = (n_queries + Q16_QPB - 1) / Q16_QPB;
     const int streams = (n_cus / 8) / nqg;
     return 4 * 8 * (streams < 1 ? 1 : streams);  // four per workgroup: one per row quarter (lane >> 4)
@@ -460,6 +470,7 @@ int crag_launch_scan_q16(const MfmaArgs& a, int mode, int n_cus, hipStream_t s) 
     if (a.row_begin % Q16_TM) return -1;
     const int nqg = (a.n_queries + Q16_QPB - 1) / Q16_QPB;
     if (nqg > 32) return -1;
+    n_cus = n_cus > 256 ? 256 : n_cus;
     int streams = (n_cus / 8) / nqg;  // row-tile streams per XCD
     if (streams < 1) streams = 1;
     const long long n_tiles = (a.row_end - a.row_begin + Q16_TM - 1) / Q16_TM;

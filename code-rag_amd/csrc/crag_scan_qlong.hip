@@ -4,7 +4,7 @@
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection, where no
 // query-stationary scan applies:
 //   * bf16 rows longer than 1024 elements: the queries do not fit a wave's registers (96 / 128 MFMA fragments per 32
-//     queries = 384 / 512 registers before the first accumulator), so crag_scan_qreg2 / qsplit stop at 1024 elements;
+//     queries = 384 / 512 registers before the first accumulator), so crag_scan_q16 / qsplit stop at 1024 elements;
 //     GEMV groups of 8 queries read the corpus B / 8 times (tools/sweep_auto.py, round 2: 256 queries on 1.3M x 1536
 //     took 16 ms, 15x the 768-element case);
 //   * float32 rows (the reference's own storage type, embed_ingest.py:93 via Chroma): the float32 matrix pipe is slow

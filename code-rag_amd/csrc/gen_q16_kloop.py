@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Generates crag_q16_kloop.inc for crag_scan_q16.hip: the per-tile statement of the query-stationary MFMA scan
-in the v_mfma_f32_16x16x32_bf16 shape.
+"""Generates crag_q16_kloop.inc for crag_scan_q16.hip: the per-tile statements of the query-stationary MFMA scan
+(v_mfma_f32_16x16x32_bf16).
 
-Same output tile per wave as crag_qreg2_kloop.inc (32 corpus rows x 64 queries, 256 queries per workgroup of four
-waves), same LDS image, same LDS-DMA, same number of LDS reads, registers and flops per tile -- only the matrix
-instruction differs: 2 row blocks x 4 query blocks of 16x16 accumulators (8 x 4 registers) instead of 2 query blocks
-of 32x32 (2 x 16).  MI355X_MICROARCH.md ("DVFS give-back", item 7) measured the 16x16x32 form at 1.12-1.14 x the FLOP/s
-of 32x32x16 on random data at equal cycles, because the chip holds a higher clock on it; this scan is power-bound
-(DESIGN.md section 5), so the shape is a lever where a tighter schedule is not.
+Output tile per wave: 32 corpus rows x 64 queries (256 queries per workgroup of four waves) = 2 row blocks x 4 query
+blocks of 16x16 accumulators (8 x 4 registers).  Every A fragment read from LDS feeds four MFMAs (one per query
+block).  The 32x32x16 form of rounds 1-2 (2 query blocks of 32x32, same tile, LDS image, LDS reads, DMA, registers and
+flops) ran at a lower clock on random data -- MI355X_MICROARCH.md ("DVFS give-back", item 7) -- and was retired after
+the same-box A/B of round 3.
 
-REGISTER FILE PARTITION (one wave per SIMD: 256 VGPRs + 256 AGPRs), as in gen_qreg2_kloop.py:
+REGISTER FILE PARTITION (one wave per SIMD: 256 VGPRs + 256 AGPRs).  At D = 768 the stationary query fragments alone
+are 96 x 4 = 384 registers; hipcc's allocator, given them as asm operands, spills them wholesale (two uses each: they
+look cold).  They are therefore kept OUT of the compiler's sight, in fixed registers that only the generated
+statements name; every statement lists them as clobbers, so the compiler holds nothing there ACROSS a statement, and
+build.py (check_q16_isa) proves on the emitted ISA that it uses none of them BETWEEN statements either:
   a[0:255], v[128:255]  query fragments: fragment n = qb * (KS / 2) + s (query block qb = 0..3, 32-element k-step s)
                         in a[4n:4n+3] for n < 64, else v[128 + 4 (n - 64) : +3]   [fixed registers, ISA-checked]
   v[96:127]             accumulators: (row block rb, query block qb) -> v[96 + 16 rb + 4 qb : +3]; pinned OUTPUTS
@@ -41,8 +44,7 @@ registers) and build.py proves on the emitted ISA that no compiler instruction o
 Q16First issues the same first reads for the tile that opens a run of Q16Fast statements.
 
 A "half-step" h = 2 s + rb multiplies row block rb of k-step s into the four query blocks: four MFMAs of 16 cycles,
-the same 64 cycles as one k-step (two MFMAs of 32) of the 32x32x16 statement, so the LDS-read distance, the DMA slots
-and the counted waits carry over one to one.  LDS address of (s, rb): (a0 ^ 64 (s & 3)) + 256 (s >> 2) + rb * 16 rows:
+64 cycles of matrix pipe.  LDS address of (s, rb): (a0 ^ 64 (s & 3)) + 256 (s >> 2) + rb * 16 rows:
 the chunk swizzle (4 s + g) ^ (row & 15) folds into one XOR because rows are multiples of 256 bytes, and rows r and
 r + 16 swizzle alike, so both row blocks share the XORed address and differ in the immediate offset.
 
@@ -102,7 +104,7 @@ TCLOB = ", ".join('"v%d"' % i for i in range(64, 96))
 print("template <int KS> struct Q16KLoop;")
 print("template <int KS> struct Q16First;")
 print("template <int KS, int PH, bool NT> struct Q16Fast;")
-for KS in (16, 24, 32, 48):  # KS = 16-element k-steps per row, as in the 32x32x16 statement; half-steps here
+for KS in (16, 24, 32, 48):  # KS = row length / 16 = half-steps per tile
     PPW = KS // WAVES
     ROWB = KS * 32
     assert KS >= 8

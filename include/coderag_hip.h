@@ -215,9 +215,7 @@ int crag_merge_rerank_device(int device, const void* entries_dev, int G, int B, 
  * re-scan (the rest of [2] were settled by re-scoring their whole candidate buffer) */
 int crag_stats(crag_index* h, int64_t* out9, int reset);
 /* force a path for tests/bench: 0 auto, 1 gemv groups, 2 mfma (the query-stationary scan where the row length has
- * one), 3 the LDS-tiled mfma scan (bf16 rows of 1536 / 2048 elements, every float32 row length; elsewhere as 2),
- * 4 / 5 as 2 with the query-stationary scan of bf16 rows up to 768 elements in the v_mfma_f32_16x16x32_bf16 /
- * v_mfma_f32_32x32x16_bf16 shape (otherwise the library's default shape, or CRAG_MFMA_SHAPE=16|32 in the environment) */
+ * one), 3 the LDS-tiled mfma scan (bf16 rows of 1536 / 2048 elements, every float32 row length; elsewhere as 2) */
 int crag_set_path(crag_index* h, int path);
 /*
  * Kernel timing for bench.py's roofline line: when on, every search brackets its two scan

@@ -285,13 +285,10 @@ def test_parity_f32_mfma_regime(coracle, d, n, nq, top_k, metric):
                                               ("f32", 768, 20, "tiled"), ("f32", 1024, 64, "tiled"), ("f32", 512, 200, "tiled"),
                                               ("f32", 384, 70, "tiled"), ("f32", 768, 96, "tiled"), ("f32", 384, 160, "tiled"),
                                               ("bf16", 1536, 128, "mfma"), ("bf16", 2048, 20, "mfma"), ("bf16", 1536, 90, "mfma"),
-                                              # both matrix shapes of the query-stationary scan, every row length, one and
-                                              # several query groups (crag_scan_qreg2.hip / crag_scan_q16.hip)
-                                              ("bf16", 768, 40, "mfma16"), ("bf16", 768, 260, "mfma16"), ("bf16", 256, 33, "mfma16"),
-                                              ("bf16", 384, 129, "mfma16"), ("bf16", 512, 256, "mfma16"), ("bf16", 512, 300, "mfma16"),
-                                              ("bf16", 384, 600, "mfma16"), ("bf16", 256, 1, "mfma16"),
-                                              ("bf16", 768, 40, "mfma32"), ("bf16", 768, 260, "mfma32"), ("bf16", 256, 33, "mfma32"),
-                                              ("bf16", 384, 129, "mfma32"), ("bf16", 512, 256, "mfma32")])
+                                              # the query-stationary scan at every row length with several query groups, and
+                                              # with a single query (three of a wave's four query blocks empty)
+                                              ("bf16", 512, 300, "mfma"), ("bf16", 384, 600, "mfma"), ("bf16", 256, 1, "mfma"),
+                                              ("bf16", 768, 1100, "mfma")])
 def test_scan_error_bound(dtype, d, nq, path):
     """The certificate assumes |approximate scan score - exact score| <= eps with
     eps = 2 * 2^-24 * ((dim_pad + 4) (2 |q||x|max + |x|max^2) + 3 |x|max^2).  Check the scans against fp64 on every
@@ -302,8 +299,6 @@ def test_scan_error_bound(dtype, d, nq, path):
     qs = O.synth_unit_rows(nq, d, 2, dtype)
     col = make_collection(rows, dtype)
     q = torch.from_numpy(qs).cuda() if dtype == "f32" else torch.from_numpy(qs.view(np.int16)).cuda().view(torch.bfloat16)
-    if path in ("mfma16", "mfma32"):
-        col.set_path(path)
     got = col.debug_dense_scores(q, path).cpu().numpy().astype(np.float64)
     X, Q = O.as_f64(rows), O.as_f64(qs)
     ref = (X * X).sum(1)[None, :] - 2.0 * Q @ X.T

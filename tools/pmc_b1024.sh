@@ -9,7 +9,7 @@ import csv, glob
 f = glob.glob("$O/**/p_counter_collection.csv", recursive=True)[0]
 best = {}
 for r in csv.DictReader(open(f)):
-    if "k_scan_qreg2" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+    if "k_scan_q16" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
         best[r["Dispatch_Id"]] = float(r["Counter_Value"])
 top = sorted(best.values())[-3:]
 print("CRAG_AHEAD_MAX=$v last-level FETCH_SIZE x2 (GB):", [round(x * 1024 * 2 / 1e9, 2) for x in top])

@@ -241,13 +241,29 @@ def main():
     col.set_profiling(False)
     prof = col.profile(reset=True)
     st = col.stats(reset=True)
+    multi = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # what the first hardware run of the scaling tier needs to be diagnosable: every rank's own step time (min / max
+        # over ranks), the world size the process group really has, and the exchange step alone (a few extra steps
+        # with device waits around the all-gather, outside the timed region)
+        own = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmin, tmax = own.clone(), own.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
         fb = torch.tensor([st["fallback"]], dtype=torch.int64, device=dev)
         dist.all_reduce(fb)
         st["fallback"] = int(fb.item())
+        sharded.timing = {}
+        for _ in range(5):
+            step()
+        ag = torch.tensor([sharded.timing["allgather_s"] / max(sharded.timing["calls"], 1)], dtype=torch.float64, device=dev)
+        sharded.timing = None
+        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+        multi = {"world_size_seen": dist.get_world_size(), "rank_step_ms_min": round(float(tmin.item()) / args.steps * 1e3, 4),
+                 "rank_step_ms_max": round(float(tmax.item()) / args.steps * 1e3, 4),
+                 "allgather_us_max_over_ranks": round(float(ag.item()) * 1e6, 1),
+                 "allgather_bytes_per_rank": B * 2 * top_k * 16, "backend": dist.get_backend()}
     ms_per_step = dt / args.steps * 1e3
     merged_qps = B * args.steps / dt      # answers per second over the whole (sharded) corpus
     # weak scaling: the unit of work is one query scored against one --rows-per-gpu shard (rows shard,
@@ -310,6 +326,8 @@ def main():
         "exact_fallback_queries": st["fallback"],
         "merged_queries_per_s": round(merged_qps, 2),
     }
+    if multi:
+        line["multi_gpu"] = multi
     line["config"]["unit"] = (
         f"one merged answer over the whole {total_rows}-row corpus; value = batch x steps / time" if strong else
         f"one query scored against one {n}-row shard (each rank scans its own rows for all {B} queries: weak scaling); "
@@ -625,21 +643,65 @@ def config_regimes(ch, torch, np, dev):
 
 
 def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
-    """The oracle's C port (oracle/crag_oracle.c: oracle_knn_fast_f32, OpenMP over rows) on the
-    host cores, on the first `sample_rows` rows; the scan is linear in rows, so q/s for the full
-    corpus is the sample rate times sample_rows/n (stated in `sample`)."""
+    """Two CPU legs on the host cores, each on the first `sample_rows` rows (the scan is linear in rows, so q/s for
+    the full corpus is the sample rate times sample_rows/n, stated in `sample`):
+      port  the oracle's C port (oracle/crag_oracle.c: oracle_knn_fast_f32, OpenMP over rows): float32 brute force +
+            (dist, id) top-2k;
+      blas  SURVEY.md section 8d line (1): numpy / BLAS float32 brute force -- |x|^2 - 2 Q X^T in row blocks (sgemm),
+            argpartition to 2*top_k per block, merge by (dist, id) -- then the oracle's rerank (R1-R5) per query.
+    `value` is the faster of the two."""
     from oracle import coracle
     coracle.build()
     m = min(sample_rows, n)
     host_rows = rows[:m].view(torch.int16).cpu().numpy().view(np.uint16)
     nq = 256
     host_q = q[:nq].view(torch.int16).cpu().numpy().view(np.uint16)
-    coracle.knn_fast_f32(host_rows[:10000], host_q[:1], 2 * top_k)  # warm the library
+    kc = 2 * top_k
+    coracle.knn_fast_f32(host_rows[:10000], host_q[:1], kc)  # warm the library
     t0 = time.perf_counter()
-    coracle.knn_fast_f32(host_rows, host_q, 2 * top_k)
+    coracle.knn_fast_f32(host_rows, host_q, kc)
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    qps_sample = nq / dt
+    port = {"value": round(nq / dt * m / n, 4), "seconds": round(dt, 2), "cores": cores,
+            "what": "oracle C port (float32 brute force + (dist,id) top-%d, OpenMP)" % kc}
+    # ---- numpy / BLAS leg (inputs converted to float32 before the clock starts: "resident" as on the GPU side)
+    blas_threads = cores
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [cores])
+    except Exception:  # noqa: BLE001
+        pass
+    X = (host_rows.astype(np.uint32) << 16).view(np.float32)
+    Q = (host_q.astype(np.uint32) << 16).view(np.float32)
+    xn = np.einsum("ij,ij->i", X, X)
+    (Q[:8] @ X[:4096].T).sum()  # warm the BLAS threads
+    blk = 131072
+    t0 = time.perf_counter()
+    best_d = np.full((nq, 0), np.inf, np.float32)
+    best_i = np.zeros((nq, 0), np.int64)
+    for lo in range(0, m, blk):
+        hi = min(m, lo + blk)
+        S = Q @ X[lo:hi].T
+        S *= -2.0
+        S += xn[lo:hi][None, :]
+        k = min(kc, hi - lo)
+        part = np.argpartition(S, k - 1, axis=1)[:, :k]
+        best_d = np.concatenate([best_d, np.take_along_axis(S, part, axis=1)], axis=1)
+        best_i = np.concatenate([best_i, part + lo], axis=1)
+        if best_d.shape[1] > 8 * kc:
+            keep = np.argpartition(best_d, kc - 1, axis=1)[:, :kc]
+            best_d, best_i = np.take_along_axis(best_d, keep, axis=1), np.take_along_axis(best_i, keep, axis=1)
+    zeros_c = np.zeros(m, np.uint8)
+    for b in range(nq):
+        order = np.lexsort((best_i[b], best_d[b]))[:kc]
+        dist = best_d[b][order] + float(np.dot(Q[b], Q[b]))  # squared L2 = |x|^2 - 2 q.x + |q|^2
+        coracle.rerank(dist, zeros_c[best_i[b][order]], np.zeros(len(order), np.uint8), top_k, 2.0)
+    dt_blas = time.perf_counter() - t0
+    blas = {"value": round(nq / dt_blas * m / n, 4), "seconds": round(dt_blas, 2), "cores": blas_threads,
+            "what": "numpy/BLAS float32: |x|^2 - 2 Q X^T in blocks of %d rows (sgemm), argpartition to %d, (dist,id) merge, "
+                    "oracle rerank" % (blk, kc), "GFLOPs": round(2.0 * nq * m * d / dt_blas / 1e9, 1)}
+    del X, S
+    fast = blas if blas["value"] >= port["value"] else port
     import importlib.util
     chroma = ("unavailable: chromadb not installed on this box (BASELINE.md 3.3), so the reference's Chroma+HybridSearcher "
               "CPU path and recall@k against its HNSW result cannot be measured; the exact search has recall 1 by construction")
@@ -656,10 +718,10 @@ def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
             chroma = chroma_baseline.run(xr, xq, top_k, exact)
         except Exception as e:  # noqa: BLE001
             chroma = f"chromadb importable, but its run failed: {type(e).__name__}: {e}"
-    return {"reference_chroma_path": chroma, "value": round(qps_sample * m / n, 4), "unit": "queries/s", "cores": cores, "kind": "port",
-            "host_cpus_visible": os.cpu_count(),
-            "sample": f"{nq} queries x first {m} of {n} rows in {dt:.2f} s (float32 brute force + (dist,id) top-{2 * top_k}, "
-                      f"OpenMP {cores} threads); value = sample q/s x {m}/{n}"}
+    return {"reference_chroma_path": chroma, "value": fast["value"], "unit": "queries/s", "cores": fast["cores"], "kind": "port",
+            "host_cpus_visible": os.cpu_count(), "port": port, "blas": blas,
+            "sample": f"{nq} queries x first {m} of {n} rows: C port {dt:.2f} s on {cores} OpenMP threads, numpy/BLAS "
+                      f"{dt_blas:.2f} s on {blas_threads} BLAS threads; value = the faster leg's sample q/s x {m}/{n}"}
 
 
 if __name__ == "__main__":

@@ -53,6 +53,10 @@ class ShardedSearcher:
         self.rank, self.world, self.group = rank, world, group
         self._entries = None
         self._stage1, self._stage2 = stage1, stage2
+        # diagnostics of the exchange step (bench.py): when `timing` is a dict, search_device() waits for the device
+        # around the all-gather and adds its seconds to timing["allgather_s"] (and counts timing["calls"]).  Off (None)
+        # in the timed region of the bench: the waits would serialise the step.
+        self.timing = None
         import torch.distributed as dist
         have = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         if have != world:
@@ -68,7 +72,16 @@ class ShardedSearcher:
             self._stage1(queries, top_k, self._entries, q_hashes, q_hash_off)
         else:
             self.col.search_local_device(queries, top_k, self._entries, q_hashes, q_hash_off)
-        gathered = all_gather_entries(self._entries, self.group)
+        if self.timing is not None and queries.is_cuda:
+            import time
+            torch.cuda.synchronize(queries.device)
+            t0 = time.perf_counter()
+            gathered = all_gather_entries(self._entries, self.group)
+            torch.cuda.synchronize(queries.device)
+            self.timing["allgather_s"] = self.timing.get("allgather_s", 0.0) + time.perf_counter() - t0
+            self.timing["calls"] = self.timing.get("calls", 0) + 1
+        else:
+            gathered = all_gather_entries(self._entries, self.group)
         if self._stage2 is not None:
             return self._stage2(gathered, self.world, b, top_k, symbol_boost)
         from .collection import merge_rerank_device

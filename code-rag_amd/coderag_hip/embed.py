@@ -8,13 +8,36 @@ the all-MiniLM-L6-v2 ONNX archive on first use.  That model is out of scope for 
 `embed_fn: List[str] -> float32[B, D]`.  This class is the default: a deterministic character
 n-gram feature hasher, 384-d and L2-normalised like MiniLM's output.  It is NOT a semantic
 model; plug the real embedder in for retrieval quality.
+
+`default_embedder()` is what `HybridSearcher()` takes when no `embed_fn` is given -- the reference constructs its
+searcher with no arguments (api/main.py:66-72): Chroma's own ONNX MiniLM when chromadb imports, built exactly as
+hybrid_search.py:23 builds it, so that a one-line swap keeps the reference's embeddings; otherwise the hashing
+stand-in, with a warning (once per process) that the results are not semantic.
 """
 from __future__ import annotations
 
+import warnings
 import zlib
-from typing import List
+from typing import Callable, List
 
 import numpy as np
+
+_warned = False
+
+
+def default_embedder() -> Callable[[List[str]], np.ndarray]:
+    global _warned
+    try:
+        from chromadb.utils import embedding_functions  # hybrid_search.py:12
+        onnx = embedding_functions.ONNXMiniLM_L6_V2()   # hybrid_search.py:23
+    except Exception:  # not installed, or its model cannot be fetched: the offline stand-in, loudly
+        if not _warned:
+            _warned = True
+            warnings.warn("coderag_hip.HybridSearcher: no embed_fn given and chromadb's ONNXMiniLM_L6_V2 is not available; "
+                          "falling back to HashingEmbedder, a character n-gram feature hasher that is NOT a semantic model. "
+                          "Pass embed_fn=<your embedder> for meaningful retrieval.", RuntimeWarning, stacklevel=3)
+        return HashingEmbedder()
+    return lambda texts: np.asarray(onnx(list(texts)), np.float32)
 
 
 class HashingEmbedder:

@@ -20,7 +20,7 @@ import numpy as np
 from .collection import GpuCollection, lowered_name_bytes, search_multi
 from ._lib import CragError
 from .config import load_retrieval_config
-from .embed import HashingEmbedder
+from .embed import default_embedder
 from . import store
 
 
@@ -109,7 +109,7 @@ class HybridSearcher:
         query never needs a collective); `device` is the single-GPU shorthand.  `config`: the retrieval knobs
         (coderag_hip.config.load_retrieval_config(); read from configs/retrieval.yaml when None)."""
         self.db_path = db_path
-        self.ef = embed_fn if embed_fn is not None else HashingEmbedder()
+        self.ef = embed_fn if embed_fn is not None else default_embedder()                # hybrid_search.py:23
         self.devices = [int(d) for d in devices] if devices else [int(device)]
         self.device = self.devices[0]
         self.config = config if config is not None else load_retrieval_config()
@@ -145,20 +145,24 @@ class HybridSearcher:
             if name in self._cols:
                 return self._cols[name]
             load_lock = self._loading.setdefault(name, threading.Lock())
-        with load_lock:  # two threads asking for one unloaded collection: the second waits and finds it loaded
-            with self._lock:
-                if name in self._cols:
-                    return self._cols[name]
-                dev = self._next_device()
-            try:
-                col = store.load_collection(self.db_path, name, device=dev)         # :33
-            except Exception:
+        try:
+            with load_lock:  # two threads asking for one unloaded collection: the second waits and finds it loaded
                 with self._lock:
-                    self._placed -= 1
-                return None                                                          # :36-39
+                    if name in self._cols:
+                        return self._cols[name]
+                    dev = self.devices[self._placed % len(self.devices)]  # the slot is TAKEN only if the load succeeds
+                try:
+                    col = store.load_collection(self.db_path, name, device=dev)     # :33
+                except Exception:
+                    return None                                                      # :36-39
+                with self._lock:
+                    self._placed += 1
+                    self._cols[name] = col
+                return col
+        finally:
+            # names come from the X-Workspace-Id header: a per-name lock must not outlive its load, found or not
             with self._lock:
-                self._cols[name] = col
-            return col
+                self._loading.pop(name, None)
 
     # ---- search ------------------------------------------------------------------------
     def _knobs(self, top_k, symbol_boost) -> Tuple[int, float]:

@@ -258,6 +258,7 @@ struct crag_index {
     std::vector<uint8_t> len_present;  // index = byte length
     int max_name_len = 0;
     int force_path = 0;
+    uint32_t* na_status = nullptr;  // pinned, device-visible certificates of crag_search_device_noalloc (made by finalize)
     int n_cus = 256;
     int profiling = 0;
     std::mutex prof_mu;
@@ -620,7 +621,6 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         HIPCHK(hipMemcpyAsync(desc_dev, ws->pinned, merged ? ws->merged_bytes : desc_bytes, hipMemcpyHostToDevice, st));
     }
     uint32_t* cnt = (uint32_t*)ws->cntst.p;
-    uint32_t* status = cnt + (size_t)B * CRAG_CNT_STRIDE;  // device-side certificates (exact fallback; no-alloc entry point)
     float* tau = (float*)ws->tau.p;
     uint32_t* sample = (uint32_t*)ws->sample.p;
     unsigned long long* cand = nullptr;
@@ -837,10 +837,13 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     f.qhash_off = (const int*)qhoff_dev;
     f.entries = entries_dev;
     // the certificates go straight to pinned host memory (device-visible): no copy-engine trip after the last kernel
-    uint32_t hst_local[CRAG_NOALLOC_MAX_B];
-    uint32_t* hst = hst_local;
+    uint32_t* hst;
     if (noalloc) {
-        f.status = status;  // device memory in the scratch array, copied back below
+        // the handle's own pinned block (crag_index_finalize made it: nothing is allocated here, and no pageable D2H
+        // copy, which the runtime would stage and wait for, follows the last kernel)
+        if (!h0->na_status) return fail(CRAG_E_STATE, "crag_search_device_noalloc: the collection was not finalized");
+        hst = h0->na_status;
+        f.status = hst;
     } else {
         if ((rc = ws->ensure_pinned_status((size_t)B))) return rc;
         hst = ws->pinned_status;
@@ -861,7 +864,6 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     bool patched = false;
 
     // ---- verify: every query must carry an exactness certificate ----
-    if (noalloc) HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
     HIPCHK(stream_wait(st));
     if (prof) {
         float ms0 = 0.f, ms1 = 0.f;
@@ -912,7 +914,6 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
             g.trusted = 2;
             if (crag_launch_rescore_wide(g, (unsigned long long*)ws->cand.p, g.B, st)) return fail(CRAG_E_HIP, "wide re-score launch failed");
             if ((rc = crag_launch_finalize(g, st))) return fail(CRAG_E_HIP, "tier-1 finalize launch failed");
-            if (noalloc) HIPCHK(hipMemcpyAsync(hst, status, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
             HIPCHK(stream_wait(st));
             patched = true;
         }
@@ -1305,6 +1306,7 @@ int crag_index_destroy(crag_index* h) {
     (void)hipSetDevice(h->device);
     if (h->owns_rows && h->rows) (void)hipFree(h->rows);
     if (h->xnorm) (void)hipFree(h->xnorm);
+    if (h->na_status) (void)hipHostFree(h->na_status);
     if (h->owns_meta) {
         if (h->name_hash) (void)hipFree(h->name_hash);
         if (h->path_class) (void)hipFree(h->path_class);
@@ -1391,6 +1393,8 @@ int crag_index_finalize(crag_index* h) {
         if (rc) return fail(CRAG_E_HIP, "row_norms launch failed");
     }
     HIPCHK(hipMemcpy(&h->max_xnorm, mx, 4, hipMemcpyDeviceToHost));
+    // certificates of crag_search_device_noalloc: that entry point may not allocate, so its pinned block is made here
+    if (!h->na_status) HIPCHK(hipHostMalloc((void**)&h->na_status, sizeof(uint32_t) * CRAG_NOALLOC_MAX_B, hipHostMallocDefault));
     h->finalized = true;
     return 0;
 }

@@ -950,7 +950,12 @@ int crag_launch_rescore_wide(const FinalizeArgs& a, unsigned long long* cand_rw,
 }
 
 int crag_launch_exact_select(const ExactSelectArgs& a, hipStream_t s) {
-    if (a.F <= 0 || a.n_max <= 0) return 0;
+    if (a.F <= 0) return 0;
+    if (a.n_max <= 0) {  // empty collections only: still write the counters the tier-2 finalize reads (k_radix_init is
+        // the one writer of the failed queries' flat counters; level 0's k_kth wrote the segment counters only)
+        hipLaunchKernelGGL(k_radix_init, dim3(a.F), dim3(256), 0, s, a.qd, a.qmap, a.kc, a.state, a.hist, a.cnt);
+        return (int)hipGetLastError();
+    }
     const long long row_blocks = (a.n_max + 255) / 256;
     if (row_blocks * a.F > 0x7fffffffll) return -2;
     hipLaunchKernelGGL(k_exact_keys_b, dim3((unsigned)(row_blocks * a.F)), dim3(256), 0, s, a.qd, a.qmap, a.F, a.queries, a.dtype,

@@ -165,8 +165,11 @@ int crag_search_device(crag_index* h, const void* queries_dev, int B, int top_k,
  * results, bit for bit.  It calls no hipMalloc / hipFree / hipHostMalloc and creates no stream or event: every
  * workspace buffer is carved from one 24 MiB `static __device__` array inside the library (each GPU the library
  * runs on holds its own copy until the process ends).
- *   limits   B <= CRAG_NOALLOC_MAX_B (64), top_k <= CRAG_MAX_TOP_K; beyond them, or if the search would need more
- *            than the array holds, CRAG_E_LIMIT and nothing is launched.
+ *   limits   B <= CRAG_NOALLOC_MAX_B (64), top_k <= CRAG_MAX_TOP_K; beyond them CRAG_E_LIMIT and nothing is launched.
+ *            (The array is sized for those limits on a 256-CU device.  Should a search still need more than it holds,
+ *            the call returns CRAG_E_LIMIT as well, but by then it may have enqueued small copies on `stream` and it
+ *            waits for the stream before it returns.)  The certificates come back through a small pinned block that
+ *            crag_index_finalize made for the handle: no device-to-host copy follows the last kernel.
  *   exactness  a query that fails its exactness certificate or overflows its candidate buffer cannot be re-run
  *            here (the exact fallback scan needs 8 bytes of workspace per row): the call returns CRAG_E_INEXACT and
  *            the caller repeats the batch through crag_search_device.  The outputs are not valid in that case.

@@ -250,6 +250,58 @@ def test_collections_are_placed_round_robin_over_the_devices(monkeypatch):
     assert ch.HybridSearcher(db_path="unused", device=2).devices == [2]
 
 
+def test_default_embedder_follows_the_reference_or_warns(monkeypatch):
+    """HybridSearcher() with no embed_fn (the reference's own construction, api/main.py:66-72): Chroma's ONNX MiniLM
+    exactly as hybrid_search.py:23 builds it when chromadb imports; otherwise the hashing stand-in WITH a warning."""
+    import sys
+    import types
+    import warnings
+    import coderag_hip.embed as E
+    # (1) chromadb absent (this container): warning once, hashing stand-in
+    monkeypatch.setitem(sys.modules, "chromadb", None)
+    monkeypatch.setattr(E, "_warned", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        hs = ch.HybridSearcher(db_path="unused")
+        ch.HybridSearcher(db_path="unused")
+    assert isinstance(hs.ef, ch.HashingEmbedder)
+    msgs = [x for x in w if "NOT a semantic model" in str(x.message)]
+    assert len(msgs) == 1 and issubclass(msgs[0].category, RuntimeWarning)
+    # (2) chromadb present: its ONNXMiniLM_L6_V2(), called with the list of texts, result as float32 [B, 384]
+    calls = []
+
+    class FakeOnnx:
+        def __call__(self, texts):
+            calls.append(list(texts))
+            return [[float(len(t))] * 384 for t in texts]
+
+    chroma = types.ModuleType("chromadb")
+    utils = types.ModuleType("chromadb.utils")
+    ef = types.ModuleType("chromadb.utils.embedding_functions")
+    ef.ONNXMiniLM_L6_V2 = FakeOnnx
+    utils.embedding_functions = ef
+    chroma.utils = utils
+    for name, mod in (("chromadb", chroma), ("chromadb.utils", utils), ("chromadb.utils.embedding_functions", ef)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                       # no warning on this branch
+        hs = ch.HybridSearcher(db_path="unused")
+    v = hs.ef(["ab", "abcd"])
+    assert calls == [["ab", "abcd"]] and v.dtype == np.float32 and v.shape == (2, 384) and v[1, 0] == 4.0
+    # an explicit embed_fn is taken as it is
+    f = lambda texts: np.zeros((len(texts), 384), np.float32)
+    assert ch.HybridSearcher(db_path="unused", embed_fn=f).ef is f
+
+
+def test_failed_collection_loads_leave_no_state_behind(monkeypatch, tmp_path):
+    """Collection names come from the X-Workspace-Id header: a name that is not on disk must leave neither a per-name
+    load lock nor a placement slot behind (hybrid_search.py:36-39 swallows the error and answers [])."""
+    hs = ch.HybridSearcher(db_path=str(tmp_path), embed_fn=ch.HashingEmbedder(), devices=[0, 1])
+    for i in range(50):
+        assert hs.search("x", collection_name=f"code_chunks__nobody{i}") == []
+    assert hs._loading == {} and hs._placed == 0 and hs._cols == {}
+
+
 def test_group_requests_one_launch_per_device_and_geometry():
     k = lambda dev, name, dim=1024, dt="bf16": (dev, dim, dt, "l2", name)
     keys = [k(0, "a"), k(1, "b"), None, k(0, "c"), k(0, "a"), k(1, "d"), k(1, "b"), k(0, "e", 384, "f32")]

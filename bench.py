@@ -282,6 +282,7 @@ def main():
     traffic, traffic_src = (pmc_traffic_checked(n, d, B) if top_k == (100 if B == 1024 else 10) and (B != 1 or args.path == "gemv") else
                             (None, "the committed passes are top-10 runs (top-100 at batch 1024; batch 1 with --path gemv)"))
     step_s = ms_per_step * 1e-3
+    prof_ms = pmc_entry(n, d, B).get("kernel_ms_kernel_trace") if traffic else None  # only while the sources match
     roofline = {
         "kernel": scan_kernel_name(d, B, args.path, n, top_k) + " (last cascade level: every row behind the earlier levels)",
         "bound": "hbm" if hbm_bound else "mfma",
@@ -292,6 +293,11 @@ def main():
         "traffic": traffic,
         "traffic_source": traffic_src,
         "kernel_ms": round(scan_ms, 4),
+        # the same launch under rocprofv3 --kernel-trace (committed profile set; a profiled launch runs a few per cent
+        # longer) and the fraction that follows from it: frac above is from this run's own HIP events
+        "kernel_ms_profiled": prof_ms,
+        "frac_profiled": (round((alg_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hbm_bound else
+                                (flops / (prof_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF), 4) if prof_ms else None),
         "algorithmic_bytes": alg_bytes,
         "rows_scanned": int(scan_rows),
         "mfma_tflops": round(flops / (scan_ms * 1e-3) / 1e12, 2) if scan_ms > 0 else 0.0,

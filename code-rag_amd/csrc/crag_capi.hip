@@ -363,7 +363,9 @@ LevelBounds cascade_bounds(long long N, long long n0, int M) {
     if (N <= n0) return nb;
     const double R = (double)N / (double)n0;
     constexpr int L_MAX = CRAG_MAX_LEVELS;
-    int L = (int)std::ceil(std::log(R) / std::log(M > 64 ? 3.0 : 6.0));
+    static const double r_small = [] { const char* e = getenv("CRAG_CASCADE_R10"); return e && atof(e) > 1.1 ? atof(e) : 6.0; }();
+    static const double r_large = [] { const char* e = getenv("CRAG_CASCADE_R100"); return e && atof(e) > 1.1 ? atof(e) : 3.0; }();
+    int L = (int)std::ceil(std::log(R) / std::log(M > 64 ? r_large : r_small));  // (the two variables: same-box sweeps only)
     L = std::max(1, std::min(L, L_MAX));
     auto est = [&](int l) { return (double)l * (double)M * std::pow(R, 1.0 / l); };
     while (L < L_MAX && est(L) > 0.75 * CRAG_CAND_CAP && est(L + 1) < est(L)) ++L;

@@ -34,6 +34,12 @@ def loop(fn):
     return (time.perf_counter() - t0) / N * 1e6
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "quick":  # under rocprofv3 --kernel-trace: a few searches, then out
+    col.set_profiling(False)
+    for i in range(20):
+        col.search_device(qs[i], 10, 2.0, out=res)
+    torch.cuda.synchronize()
+    sys.exit(0)
 for prof in (True, False):
     col.set_profiling(prof)
     print(f"python wrapper, profiling={prof}: {loop(lambda i: col.search_device(qs[i % 64], 10, 2.0, out=res)):.1f} us", flush=True)

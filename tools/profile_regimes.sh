@@ -23,7 +23,19 @@ run b1024 "" --batch 1024 --top-k 100 --no-extras --steps 10 --warmup 2
 run b1024 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --batch 1024 --top-k 100 --no-extras --steps 5 --warmup 2
 mv $O/pmc_b1024 $O/pmc_b1024_mfma
 run b1024 "FETCH_SIZE" --batch 1024 --top-k 100 --no-extras --steps 5 --warmup 2
+mv $O/pmc_b1024 $O/pmc_b1024_fetch
+# where a wave's cycles go (MI355X_MICROARCH.md, rocprofv3 PMC slots): parked in s_waitcnt / barrier, issue stalls, issuing
+run b1024 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_BUSY_CYCLES" --batch 1024 --top-k 100 --no-extras --steps 5 --warmup 2
+mv $O/pmc_b1024 $O/pmc_b1024_sq
+mv $O/pmc_b1024_fetch $O/pmc_b1024
 run b8 "" --batch 8 --no-extras --steps 10 --warmup 2
 run b8 "FETCH_SIZE" --batch 8 --no-extras --steps 5 --warmup 2
+# configs[3] at one GPU (100M x 768 bf16, 153.6 GB resident): why is its last level slower per row than on 10M rows?
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $O/kt_b256_100m -o b256_100m --output-format csv -- python3 bench.py --rows-per-gpu 100000000 --no-extras --steps 4 --warmup 2 > $O/kt_b256_100m.log 2>&1 || true
+timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc_b256_100m -o b256_100m --output-format csv -- python3 bench.py --rows-per-gpu 100000000 --no-extras --steps 3 --warmup 1 > $O/pmc_b256_100m.log 2>&1 || true
+timeout -s KILL 150 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $O/pmc_b256_clk -o b256_clk --output-format csv -- python3 bench.py --no-extras --steps 5 --warmup 2 > $O/pmc_b256_clk.log 2>&1 || true
+# configs[1] (1M x 384 fp32, one query per call): kernel timeline of a single synchronous caller
+timeout -s KILL 150 rocprofv3 --kernel-trace -d $O/kt_c2 -o c2 --output-format csv -- python3 tools/latency_c2.py quick > $O/kt_c2.log 2>&1 || true
+python3 tools/trace_timeline.py $(find $O/kt_c2 -name "c2_kernel_trace.csv" | head -1) 16 > $O/c2_timeline.txt 2>&1 || true
 timeout -k 10 300 python3 bench.py > $O/bench_full.log 2>&1
 tail -n 1 $O/bench_full.log | cut -c1-300

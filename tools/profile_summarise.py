@@ -82,6 +82,49 @@ for name, B in (("b256", 256), ("b1", 1), ("b8", 8), ("b1024", 1024)):
 with open(f"{src}/bench_full.log") as f:
     line = [l for l in f if l.startswith("{")][-1]
 open(f"profiles/{tag}_bench_full_line.json", "w").write(line)
+# the same launches timed by the bench's own HIP events WITHOUT the profiler, same lease: a launch under rocprofv3
+# runs a few per cent longer, so roofline.frac (events) and roofline.frac_profiled (kernel trace) are both on record
+full = json.loads(line)
+unprof = {"b256": full["roofline"]["kernel_ms"]}
+for r in full.get("regimes", []):
+    for name, key in (("b1", "batch-1 top-10 GEMV"), ("b8", "batch-8 top-10 MFMA"), ("b1024", "batch-1024 top-100")):
+        if r.get("regime", "").startswith(key):
+            unprof[name] = r["scan_kernel_ms"]
+for name, ms in unprof.items():
+    summary[name]["last_level_ms_hip_events_unprofiled_same_lease"] = ms
+    summary[name]["profiled_over_unprofiled"] = round(summary[name]["last_level_avg_ms"] / ms, 4)
+    traffic[f"10000000|768|{ {'b256': 256, 'b1': 1, 'b8': 8, 'b1024': 1024}[name] }"]["kernel_ms_hip_events_unprofiled"] = ms
+# batch-1024: where a wave's cycles go
+try:
+    pm3 = filt(find("pmc_b1024_sq/**/b1024_counter_collection.csv"), f"profiles/{tag}_b1024_sq_pmc.csv", "Kernel_Name")
+    b3 = max(scan_counters(pm3).values(), key=lambda c: c.get("SQ_WAVE_CYCLES", 0))
+    wc = b3["SQ_WAVE_CYCLES"]
+    summary["b1024"]["wave_cycle_shares"] = {k: round(b3[k] / wc, 4) for k in b3 if k != "SQ_WAVE_CYCLES" and k != "SQ_BUSY_CYCLES"}
+    summary["b1024"]["clock_GHz_gui_active"] = round(summary["b1024"]["mfma_counters_of_one_last_level_launch"]["GRBM_GUI_ACTIVE"] / 8 /
+                                                      (summary["b1024"]["last_level_avg_ms"] * 1e-3) / 1e9, 3)
+except SystemExit:
+    pass
+# configs[3] at one GPU against the 10M-row shard: duration per row, traffic per row, clock
+try:
+    tr = list(csv.DictReader(open(find("kt_b256_100m/**/b256_100m_kernel_trace.csv"))))
+    filt(find("kt_b256_100m/**/b256_100m_kernel_stats.csv"), f"profiles/{tag}_b256_100m_kernel_stats.csv", "Name")
+    scans = [r for r in tr if "k_scan_" in r["Kernel_Name"]]
+    dur = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in scans)
+    longest = [d for d in dur if d > 0.5 * dur[-1]]
+    pm = filt(find("pmc_b256_100m/**/b256_100m_counter_collection.csv"), f"profiles/{tag}_b256_100m_pmc.csv", "Kernel_Name")
+    big = max(scan_counters(pm).values(), key=lambda c: c.get("FETCH_SIZE", 0))
+    pmc = filt(find("pmc_b256_clk/**/b256_clk_counter_collection.csv"), f"profiles/{tag}_b256_clk_pmc.csv", "Kernel_Name")
+    small = max(scan_counters(pmc).values(), key=lambda c: c.get("GRBM_GUI_ACTIVE", 0))
+    ms100 = sum(longest) / len(longest) / 1e6
+    summary["b256_100m"] = {"last_level_avg_ms": ms100, "hbm_bytes_per_launch": big["FETCH_SIZE"] * 1024 * 2,
+                            "clock_GHz_gui_active": round(big["GRBM_GUI_ACTIVE"] / 8 / (ms100 * 1e-3) / 1e9, 3),
+                            "clock_GHz_gui_active_10m_rows": round(small["GRBM_GUI_ACTIVE"] / 8 / (summary["b256"]["last_level_avg_ms"] * 1e-3) / 1e9, 3)}
+except SystemExit:
+    pass
+try:
+    open(f"profiles/{tag}_c2_timeline.txt", "w").write(open(f"{src}/c2_timeline.txt").read())
+except OSError:
+    pass
 json.dump(summary, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -55,7 +55,7 @@ DIST = int(os.environ.get("Q16_DIST", "3"))  # half-steps an LDS read runs ahead
 NT, WAVES = DIST + 2, 4
 PRE = DIST + 1  # fragments read ahead of a tile's first MFMA (by the previous statement in the steady state)
 SPREAD = os.environ.get("Q16_ORDER", "spread") != "clump"
-ABL = os.environ.get("Q16_ABL", "")  # ablation builds for tools/qreg_bench.hip only: nodma | noepi | nomfma
+ABL = set(filter(None, os.environ.get("Q16_ABL", "").split(",")))  # (comma-separated) ablation builds for tools/q16_bench.hip only: nodma | noepi | nomfma | nolds | nobar
 # rotating A fragments: five in v[76:95]; a sixth (DIST = 4) takes over v[68:71], free once the first MFMAs have read their C
 T = [f"v[{76 + 4 * i}:{79 + 4 * i}]" for i in range(5)] + ["v[68:71]"] * (NT - 5)
 assert NT <= 6
@@ -205,17 +205,17 @@ for KS in (16, 24, 32, 48):  # KS = row length / 16 = half-steps per tile
             L.append(f"s_mov_b32 {keep}, m0")                     # it only makes the counted waits stricter while in flight
             slots = []  # (half-step, M0 of the piece, the load): M0 is set right behind the previous piece
             for h in range(KS):
-                if h % 4 == PH and ABL != "nodma":
+                if h % 4 == PH and "nodma" not in ABL:
                     i, hh = (h // 4) % (PPW // 2), (h // 4) // (PPW // 2)  # piece i of tile half hh (rows 16 hh ..)
                     slots.append((h, f"s_add_u32 m0, {ldst}, {(i * WAVES + hh * (KS // 2)) * 1024}", f"global_load_lds_dwordx4 {voff[i]}, {base[hh]}{ntbit}"))
-                if h == 4 + (PH + 2) % 4 and ABL != "nodma":
+                if h == 4 + (PH + 2) % 4 and "nodma" not in ABL:
                     slots.append((h, f"s_mov_b32 m0, {xdst}", f"global_load_lds_dword {xoff}, {xbase}{ntbit}"))
-            assert len(slots) == PPW + 1 or ABL == "nodma"
+            assert len(slots) == PPW + 1 or "nodma" in ABL
             if slots:
                 L.append(slots[0][1])
             nslot = 0
             for h in range(KS):
-                m = mfmas(h) if ABL != "nomfma" else [None] * 4
+                m = mfmas(h) if "nomfma" not in ABL else [None] * 4
                 here = []
                 while nslot < len(slots) and slots[nslot][0] == h:
                     here.append(slots[nslot][2])
@@ -245,14 +245,17 @@ for KS in (16, 24, 32, 48):  # KS = row length / 16 = half-steps per tile
             # end of tile: every wave retires all but the DMA instructions of THIS statement (its youngest; tile t + step
             # has then landed in its view), the barrier makes that true for all four, and the next tile's first reads go out
             L.append(f"s_waitcnt vmcnt({len(slots)}) lgkmcnt(0)")
-            L.append("s_barrier")
+            if "nobar" not in ABL:  # (timing ablation only: racy)
+                L.append("s_barrier")
             first_reads(L, [], a0n, xan, ROWB)
             # (the wait, the barrier and these ten instructions stand between the last MFMA and the VALU reads of its result)
-            if ABL == "noepi":
+            if "noepi" in ABL:
                 L += [f"v_mov_b32 {m}, 0x7f800000" for m in mn]
             else:
                 L.append("s_nop 1")
                 min_tree(L, mn)
+            if "nolds" in ABL:  # (timing ablation only: the MFMAs multiply whatever the registers hold)
+                L = [x for x in L if not x.startswith("ds_read")]
             body = "\\n\\t".join(L)
             outs = ", ".join(f'"{c}"({e})' for c, e in ops[:n_out])
             ins = ", ".join(f'"{c}"({e})' for c, e in ops[n_out:])

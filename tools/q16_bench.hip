@@ -4,7 +4,10 @@
 // end-of-tile vmcnt wait and pacing / barrier), medians over the waves, after >= 2 s of back-to-back launches.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DQ16_PROFILE=1048576 -o tools/bin/q16_prof tools/q16_bench.hip
 //   tools/bin/q16_prof <B> [z|r] [tau] [rows]
-#include "../code-rag_amd/csrc/crag_scan_q16.hip"
+#ifndef Q16_SRC
+#define Q16_SRC "../code-rag_amd/csrc/crag_scan_q16.hip"
+#endif
+#include Q16_SRC
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -27,7 +30,9 @@ int main(int argc, char** argv) {
     MfmaArgs a; memset(&a, 0, sizeof(a)); a.rows = rows; a.xnorm = xn; a.n_rows = n; a.row_begin = 0; a.row_end = n; a.queries = q; a.n_queries = B;
     a.dim_pad = D; a.metric = CRAG_L2; a.tau = tau; a.cand = cand; a.cnt = cnt;
     a.segcnt = cnt; a.n_seg = crag_q16_segments(B, 256); a.seg_cap = std::max(32, 2 * CRAG_CAND_CAP / a.n_seg); a.cand_stride = (long long)a.n_seg * a.seg_cap;
-    a.progress = B > 256 ? prog : nullptr; a.ahead_max = 4;
+    // Q16_AHEAD: tiles ahead | (pace mask << 8) as MfmaArgs::ahead_max; 0 = no pacing (no progress words)
+    const int ahead = getenv("Q16_AHEAD") ? atoi(getenv("Q16_AHEAD")) : (CRAG_AHEAD_MAX_DEFAULT | ((CRAG_PACE_EVERY_DEFAULT - 1) << 8));
+    a.progress = (B > 256 && (ahead & 0xff)) ? prog : nullptr; a.ahead_max = ahead;
     auto launch = [&]() { if (a.progress) (void)hipMemsetAsync(prog, 0, 4 * CRAG_PROGRESS_WORDS(256), nullptr); return crag_launch_scan_q16(a, 1, 256, nullptr); };
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int reps = (int)std::max(20.0, 2.5e3 / (2.0 * B * n * D / 1.3e12));  // >= 2 s back to back

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     if (n_fast > 0) {
         auto fast = [&](auto ph) {
             constexpr int PH = decltype(ph)::value;
-            Q16First<KS>::run(a_lane + cur * STAGE, x_lane + cur * x_step);
+            // the run starts on ring buffer 0 (it follows the prologue directly)
+            Q16First<KS>::run(a_lane, x_lane);
             Q16Dma<PPW> d;
 #pragma unroll
             for (int i = 0; i < HP; ++i) d.voff[i] = voff[i];
@@ -309,10 +310,11 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
             const long long xn_inc = t_step * Q16_TM;
             unsigned tile32 = (unsigned)t;
             const unsigned step32 = (unsigned)t_step;
-            unsigned left = (unsigned)n_fast;  // < 2^27 tiles
-            int nxt = cur + 1 == Q16_NSTAGE ? 0 : cur + 1;
-            do {
-                const int nxt2 = nxt + 1 == Q16_NSTAGE ? 0 : nxt + 1;
+            // one tile on ring buffer CUR: every address that depends on the buffer is a loop-invariant register (the
+            // loop below is unrolled over the three buffers), so a tile costs the pointer increments and nothing else
+            auto one = [&](auto cur_tag) {
+                constexpr int CUR = decltype(cur_tag)::value;
+                constexpr int NXT = (CUR + 1) % Q16_NSTAGE, NXT2 = (CUR + 2) % Q16_NSTAGE;
                 if constexpr (PH == 0 && !NT) {
                     // wave 0 of a workgroup that shares its tiles, every (pace_mask + 1)-th tile: publish the tile count, then
                     // wait for the slowest partner.  (Every tile cost the whole workgroup ~80 cycles per tile behind wave 0:
@@ -337,17 +339,17 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
                     ++tiles_done;
                 }
                 d.tile_hi = d.tile + HALF;
-                d.lds_dst = lds_base + nxt2 * STAGE + wave * 1024;
-                d.xn_dst = lds_base + XN_BASE + (nxt2 * Q16_WAVES + wave) * Q16_XN_BYTES;
+                d.lds_dst = lds_base + NXT2 * STAGE + wave * 1024;
+                d.xn_dst = lds_base + XN_BASE + (NXT2 * Q16_WAVES + wave) * Q16_XN_BYTES;
                 f32x16_t acc0, acc1;  // row block rb: element 4 jb + e = SCORE of row 16 rb + 4 fg + e against the query of block jb
                 float mn0, mn1, mn2, mn3;
 #ifdef Q16_PROFILE
                 const unsigned long long prof_s0 = Q16_PROF_NOW();
 #endif
                 if constexpr (PH == 0 && !NT)
-                    Q16Fast<KS, 0, false>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + nxt * STAGE, x_lane + nxt * x_step, d, pp, pv);
+                    Q16Fast<KS, 0, false>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + NXT * STAGE, x_lane + NXT * x_step, d, pp, pv);
                 else
-                    Q16Fast<KS, PH, NT>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + nxt * STAGE, x_lane + nxt * x_step, d);
+                    Q16Fast<KS, PH, NT>::run(acc0, acc1, mn0, mn1, mn2, mn3, a_lane + NXT * STAGE, x_lane + NXT * x_step, d);
 #ifdef Q16_PROFILE
                 const unsigned long long prof_s1 = Q16_PROF_NOW();
 #endif
@@ -357,12 +359,19 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
                 prof_slow += Q16_PROF_NOW() - prof_s1;
                 ++prof_tiles;
 #endif
-                cur = nxt;
-                nxt = nxt2;
                 d.tile += tile_inc;
                 d.xn += xn_inc;
                 tile32 += step32;
-            } while (--left);
+            };
+            const unsigned rem = (unsigned)(n_fast % Q16_NSTAGE);  // n_fast < 2^27 tiles
+            for (unsigned left = (unsigned)(n_fast / Q16_NSTAGE); left; --left) {
+                one(std::integral_constant<int, 0>{});
+                one(std::integral_constant<int, 1>{});
+                one(std::integral_constant<int, 2>{});
+            }
+            if (rem >= 1) one(std::integral_constant<int, 0>{});
+            if (rem >= 2) one(std::integral_constant<int, 1>{});
+            cur = (int)rem;
         };
         switch (wave) {  // the DMA slots of the statement are staggered by wave
             case 0: fast(std::integral_constant<int, 0>{}); break;

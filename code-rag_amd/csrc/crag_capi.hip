@@ -666,7 +666,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         ma.xnorm = h0->xnorm;
         ma.n_rows = h0->n_rows;
         ma.queries = q_dev;
-        if (segmented) {  // its accumulators are the scores: B operand = -2 q (l2) / -q (ip), once per search
+        if (segmented || qsplit) {  // their accumulators are the scores: B operand = -2 q (l2) / -q (ip), once per search
             if ((rc = ws->qscan.ensure((size_t)B * h0->dim_pad * 2))) return rc;
             if (crag_q16_scale_queries(q_dev, B, h0->dim_pad, h0->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
             ma.queries = ws->qscan.p;
@@ -1616,7 +1616,7 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         rowmajor = true;
         bpad = ((long long)B + 15) / 16 * 16;
         tiled = d_qreg2;  // crag_launch_scan_q16's tile-major sample
-        if (d_qreg2) {
+        if (d_qreg2 || d_qsplit) {
             if ((rc = ws->qscan.ensure((size_t)B * h->dim_pad * 2))) return rc;
             if (crag_q16_scale_queries(q, B, h->dim_pad, h->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
             a.queries = ws->qscan.p;

@@ -4,12 +4,14 @@
 // Replaces the k-NN half of `col.query(..., n_results=2*top_k)` at
 // /root/reference/retriever/hybrid_search.py:60-64 for a batch of queries against one collection.
 //
-// The one-block query-stationary dataflow (crag_scan_qreg2.hip is the two-block form): four waves (one per SIMD) x 32 stationary queries, corpus tiles of
-// 32 rows streamed HBM -> LDS by LDS-DMA, fused threshold filter with the query on the lane.  A 32-row tile
+// The query-stationary dataflow of crag_scan_q16.hip with 32 instead of 64 queries per wave (1024-element queries
+// are twice as many registers): four waves (one per SIMD) x 32 stationary queries, corpus tiles of
+// 32 rows streamed HBM -> LDS by LDS-DMA, fused threshold filter with the query on the lane (lane & 15 of each of the
+// wave's two 16-query blocks; v_mfma_f32_16x16x32_bf16; the accumulators are the scores: pre-scaled queries, C = |x|^2).  A 32-row tile
 // of 2-KiB rows does not fit a three-deep LDS ring, so it travels as two half-tiles of 32 rows x 512
 // elements (K-parts) through a ring of FOUR 32-KiB buffers, three half-tiles in flight; one generated
 // statement (crag_qsplit_kloop.inc, gen_qsplit_kloop.py holds the register contract and the wait counts)
-// multiplies both K-parts of a tile into one accumulator, with the mid-tile rendezvous inside.  The 64
+// multiplies both K-parts of a tile into one set of accumulators, with the mid-tile rendezvous inside.  The 64
 // query fragments fill all 256 AGPRs (fixed registers outside the compiler's allocation, checked on the
 // emitted ISA by build.py).  Candidate appends use a flat per-query buffer + a returning atomic.
 //
@@ -31,12 +33,9 @@ constexpr int QS_HALF = QS_TM * QS_HROWB;  // bytes per LDS buffer
 constexpr int QS_NBUF = 4;
 constexpr int QS_XN_BYTES = 256;
 constexpr int QS_XN_BASE = QS_NBUF * QS_HALF;  // |x|^2 slots: [buffer][wave][64 floats]
+constexpr int QS_ZERO_BASE = QS_XN_BASE + QS_NBUF * QS_WAVES * QS_XN_BYTES;  // 256 zero bytes: the "|x|^2" of the ip metric
 constexpr int QS_DMA_PER_HALF = 9;   // per wave: 8 row pieces + the |x|^2 column
 
-struct QsplitEpi {
-    float c, w;       // score = c * (q . x) + w * |x|^2   (l2: -2, 1; ip: -1, 0)
-    unsigned xaddr;   // LDS address of the lane's |x|^2 run
-};
 struct QsplitDma {            // one half-tile to prefetch (all wave-uniform)
     const unsigned char* lo;  // first byte of the half-tile's rows 0..15 (row stride QS_GROWB)
     const unsigned char* hi;  // ... rows 16..31
@@ -48,11 +47,11 @@ struct QsplitDma {            // one half-tile to prefetch (all wave-uniform)
 #include "crag_qsplit_kloop.inc"
 
 // NT: one query group per launch, so every tile is read by exactly one workgroup: nontemporal DMA loads (see
-// crag_scan_qreg2.hip)
+// crag_scan_q16.hip)
 template <int MODE, bool NT>
 __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned short* __restrict__ rows,
                                                                   const float* __restrict__ xnorm, long long row_begin,
-                                                                  long long row_end, const unsigned short* __restrict__ queries,
+                                                                  long long row_end, const unsigned short* __restrict__ queries /* pre-scaled: -2 q (l2), -q (ip) */,
                                                                   int n_queries, int nqg, int metric,
                                                                   const float* __restrict__ tau, uint32_t* __restrict__ sample,
                                                                   long long sample_stride, unsigned long long* __restrict__ cand,
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fr = lane & 15, fg = lane >> 4;  // query column of both 16-query blocks; row quarter
 
     // workgroup -> (query group, row-tile stream); workgroups with equal blockIdx % 8 share an XCD
     const int b = blockIdx.x;
@@ -76,12 +75,14 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
 
     const int q_base = qg * QS_QPB + wave * 32;
     const bool wave_active = q_base < n_queries;  // wave-uniform
-    const int my_q = q_base + fr;
-    const bool q_ok = my_q < n_queries;
-    // stationary B operand: this lane's query, k = 16 s + 8 fh + [0,8), in fixed AGPRs
-    qsplit_load(queries + (long long)(q_ok ? my_q : n_queries - 1) * QS_D + 8 * fh);
-    float tq = -__builtin_inff();
-    if (MODE == 1 && q_ok) tq = tau[my_q];
+    const int q0 = q_base + fr, q1 = q_base + 16 + fr;
+    const bool ok0 = q0 < n_queries, ok1 = q1 < n_queries;
+    // stationary B operands: this lane's two queries, k = 32 s + 8 fg + [0,8), in fixed AGPRs
+    qsplit_load(queries + (long long)(ok0 ? q0 : n_queries - 1) * QS_D + 8 * fg,
+                queries + (long long)(ok1 ? q1 : n_queries - 1) * QS_D + 8 * fg);
+    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
+    if (MODE == 1 && ok0) tq0 = tau[q0];
+    if (MODE == 1 && ok1) tq1 = tau[q1];
 
     // LDS-DMA: a wave moves rows wave + 4 i and wave + 4 i + 16 (i < 4) of a half-tile, one 1-KiB piece per
     // row; LDS position p of row r holds chunk p ^ (r & 15), rows r and r + 16 swizzle alike
@@ -129,11 +130,12 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
                                          4, 0, NT ? 2 : 0);
     };
 
-    const unsigned a_lane = lds_base + fr * QS_HROWB + ((fh ^ (fr & 15)) << 4);
-    const unsigned x_lane = lds_base + QS_XN_BASE + wave * QS_XN_BYTES + 16 * fh;
-    QsplitEpi e;
-    e.c = metric == CRAG_L2 ? -2.f : -1.f;
-    e.w = metric == CRAG_L2 ? 1.f : 0.f;
+    const unsigned a_lane = lds_base + fr * QS_HROWB + ((fg ^ fr) << 4);
+    // C operand of a tile's first MFMAs: the lane's |x|^2 runs (l2) or zeros (ip: the score is -q.x alone)
+    const bool l2 = metric == CRAG_L2;
+    const unsigned x_lane = lds_base + (l2 ? QS_XN_BASE + wave * QS_XN_BYTES : QS_ZERO_BASE) + 16 * fg;
+    const unsigned x_step = l2 ? QS_WAVES * QS_XN_BYTES : 0;
+    if (tid < 64) ((unsigned*)(lds + QS_ZERO_BASE))[tid] = 0u;  // visible to every wave behind the prologue's barrier
 
     // half-tile h of this workgroup's sequence lives in buffer h % 4; tile i = half-tiles 2 i (part 0) and 2 i + 1.
     // prologue: half-tiles 0, 1, 2 in flight, wait for the first
@@ -160,44 +162,51 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
         if (wave_active) {
             if (ex3 && !dma0) issue(t1, 1, b3);  // ragged next tile: up front (buffer h + 3 = h - 1 is free)
             const unsigned a0 = a_lane + cur * QS_HALF, a1 = a_lane + b1 * QS_HALF;
-            e.xaddr = x_lane + b1 * (QS_WAVES * QS_XN_BYTES);
-            f32x16_t acc, xs;
-            float mn;
+            const unsigned xaddr = x_lane + cur * x_step;  // both half-tiles of a tile carry its |x|^2 column
+            f32x16_t acc;  // element 8 rb + 4 jb + e = SCORE of row 16 rb + 4 fg + e against the query of block jb
+            float mn0, mn1;
             QsplitDma d0 = half_desc(t1, 1, b3), d1 = half_desc(t2, 0, b4);
-            if (dma0 && dma1) QsplitTile<true, true, NT>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
-            else if (dma0) QsplitTile<true, false, NT>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
-            else if (dma1) QsplitTile<false, true, NT>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
-            else QsplitTile<false, false, false>::run(acc, xs, mn, a0, a1, e, voff, xoff, d0, d1);
+            if (dma0 && dma1) QsplitTile<true, true, NT>::run(acc, mn0, mn1, a0, a1, xaddr, voff, xoff, d0, d1);
+            else if (dma0) QsplitTile<true, false, NT>::run(acc, mn0, mn1, a0, a1, xaddr, voff, xoff, d0, d1);
+            else if (dma1) QsplitTile<false, true, NT>::run(acc, mn0, mn1, a0, a1, xaddr, voff, xoff, d0, d1);
+            else QsplitTile<false, false, false>::run(acc, mn0, mn1, a0, a1, xaddr, voff, xoff, d0, d1);
             if (ex4 && !dma1) issue(t2, 0, b4);  // ragged: after the mid-tile rendezvous freed buffer h
             drained = !(dma0 && dma1);
-            const unsigned mb = (unsigned)t * QS_TM + 4 * fh, re = (unsigned)row_end;  // rows per collection < 2^32
+            const unsigned mb = (unsigned)t * QS_TM + 4 * fg, re = (unsigned)row_end;  // rows per collection < 2^32
             if (MODE == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned m = mb + 8 * (r >> 2) + (r & 3);
-                    if (q_ok && m < re) sample[m * sample_stride + my_q] = crag_fkey(fmaf(e.c, acc[r], xs[r]));
+                for (int r = 0; r < 16; ++r) {  // r = 8 rb + 4 jb + e
+                    const unsigned m = mb + 16 * (r >> 3) + (r & 3);
+                    const int q = (r & 4) ? q1 : q0;
+                    if (((r & 4) ? ok1 : ok0) && m < re) sample[m * sample_stride + q] = crag_fkey(acc[r]);
                 }
                 drained = true;
-            } else if (__any(mn <= tq)) {
-                // one returning atomic per lane (= per query) for all of its passing rows
-                int npass = 0;
+            } else if (__any(mn0 <= tq0 || mn1 <= tq1)) {
+                // one returning atomic per lane and query block for all of its passing rows
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned m = mb + 8 * (r >> 2) + (r & 3);
-                    npass += (fmaf(e.c, acc[r], xs[r]) <= tq && m < re) ? 1 : 0;
-                }
-                if (npass) {
-                    int qa = my_q;
-                    asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path
-                    unsigned pos = atomicAdd(&cnt[CRAG_CNT(qa)], (unsigned)npass);
-                    unsigned long long* cq = cand + (long long)qa * CRAG_CAND_CAP;
+                for (int jb = 0; jb < 2; ++jb) {
+                    const float tq = jb ? tq1 : tq0;
+                    if ((jb ? mn1 : mn0) <= tq) {
+                        int npass = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned m = mb + 8 * (r >> 2) + (r & 3);
-                        const float s = fmaf(e.c, acc[r], xs[r]);
-                        if (s <= tq && m < re) {
-                            if (pos < CRAG_CAND_CAP) cq[pos] = ((unsigned long long)crag_fkey(s) << 32) | (unsigned long long)m;
-                            ++pos;
+                        for (int r = 0; r < 8; ++r) {  // r = 4 rb + e
+                            const unsigned m = mb + 16 * (r >> 2) + (r & 3);
+                            npass += (acc[8 * (r >> 2) + 4 * jb + (r & 3)] <= tq && m < re) ? 1 : 0;
+                        }
+                        if (npass) {
+                            int qa = jb ? q1 : q0;
+                            asm volatile("" : "+v"(qa));  // address arithmetic stays on this rare path
+                            unsigned pos = atomicAdd(&cnt[CRAG_CNT(qa)], (unsigned)npass);
+                            unsigned long long* cq = cand + (long long)qa * CRAG_CAND_CAP;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const unsigned m = mb + 16 * (r >> 2) + (r & 3);
+                                const float sc = acc[8 * (r >> 2) + 4 * jb + (r & 3)];
+                                if (sc <= tq && m < re) {
+                                    if (pos < CRAG_CAND_CAP) cq[pos] = ((unsigned long long)crag_fkey(sc) << 32) | (unsigned long long)m;
+                                    ++pos;
+                                }
+                            }
                         }
                     }
                 }
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
 
 template <int MODE, bool NT>
 int launch_one(const MfmaArgs& a, int grid, int nqg, hipStream_t s) {
-    const size_t lds = (size_t)QS_NBUF * QS_HALF + (size_t)QS_NBUF * QS_WAVES * QS_XN_BYTES;
+    const size_t lds = (size_t)QS_NBUF * QS_HALF + (size_t)QS_NBUF * QS_WAVES * QS_XN_BYTES + 256;
     static std::atomic<uint64_t> lds_ok;
     crag_allow_dynamic_lds((const void*)k_scan_qsplit<MODE, NT>, lds, lds_ok);
     hipLaunchKernelGGL((k_scan_qsplit<MODE, NT>), dim3(grid), dim3(64 * QS_WAVES), lds, s, (const unsigned short*)a.rows, a.xnorm,

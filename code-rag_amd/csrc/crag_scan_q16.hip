@@ -109,6 +109,9 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     static_assert(PIECES % Q16_WAVES == 0, "pieces must split evenly over the waves");
     static_assert(ROWB % 256 == 0, "the XOR address form needs 256-byte rows");
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];  // the ONLY LDS object
+#ifdef Q16_PROFILE
+    const unsigned long long prof_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
         pc[1] = __builtin_amdgcn_s_memrealtime() - prof_r0;
         pc[2] = prof_stmt;
         pc[3] = prof_slow;
-        pc[4] = 0;
-        pc[5] = 0;
+        pc[4] = prof_entry;  // absolute 100 MHz stamps: kernel entry, end of the prologue
+        pc[5] = prof_r0;
         pc[6] = prof_tiles;
         pc[7] = wave_active ? 1 : 0;
     }

@@ -43,21 +43,36 @@ int main(int argc, char** argv) {
     printf("B=%d rows=%lld  %.3f ms  %.1f GB/s  %.1f TFLOP/s = %.3f of 2500  (%d launches, %s)\n", B, n, ms, n * D * 2.0 / ms / 1e6, 2.0 * B * n * D / ms / 1e9,
            2.0 * B * n * D / ms / 1e9 / 2500, reps, hipGetErrorString(hipGetLastError()));
 #ifdef Q16_PROFILE
+    // one isolated launch for the timeline of a launch (its stamps are the ones read below)
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms1; (void)hipEventElapsedTime(&ms1, e0, e1);
     const int nqg = (B + 255) / 256, grid_waves = 8 * std::max(1, 32 / nqg) * nqg * 4;
     std::vector<unsigned long long> pc((size_t)grid_waves * 8);
     (void)hipMemcpy(pc.data(), cnt + Q16_PROFILE, pc.size() * 8, hipMemcpyDeviceToHost);
-    std::vector<double> clk, stmt, slow, wait, bar, per_tile;
+    std::vector<double> clk, stmt, slow, per_tile, entry, pro, fin;
     for (int w = 0; w < grid_waves; ++w) {
         const unsigned long long* p = &pc[(size_t)w * 8];
         if (!p[7] || !p[6] || !p[1]) continue;
         clk.push_back(100e6 * (double)p[0] / (double)p[1] / 1e9);
-        stmt.push_back((double)p[2] / p[0]); slow.push_back((double)p[3] / p[0]); wait.push_back((double)p[4] / p[0]); bar.push_back((double)p[5] / p[0]);
+        stmt.push_back((double)p[2] / p[0]); slow.push_back((double)p[3] / p[0]);
+        entry.push_back((double)p[4]); pro.push_back(((double)p[5] - (double)p[4]) / 100.0); fin.push_back((double)p[5] + (double)p[1]);
         per_tile.push_back((double)p[0] / p[6]);
     }
     auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
     printf("in-kernel clock %.3f GHz (median of %zu waves; min %.3f max %.3f)   cycles per tile %.0f (MFMA issue alone: 3072)\n", med(clk), clk.size(),
            clk.empty() ? 0.0 : clk.front(), clk.empty() ? 0.0 : clk.back(), med(per_tile));
-    printf("share of the tile loop: statement %.3f  hit test + slow path %.3f  vmcnt wait + pacing %.3f  barrier %.3f\n", med(stmt), med(slow), med(wait), med(bar));
+    printf("share of the tile loop: statement %.3f  hit test + slow path %.3f\n", med(stmt), med(slow));
+    // timeline of the isolated launch, microseconds from the first wave's entry
+    if (!entry.empty()) {
+        const double t0 = *std::min_element(entry.begin(), entry.end());
+        for (auto& v : entry) v = (v - t0) / 100.0;
+        for (auto& v : fin) v = (v - t0) / 100.0;
+        const double e_med = med(entry), e_max = entry.back(), p_med = med(pro), p_max = pro.back();
+        const double f_med = med(fin), f_min = fin.front(), f_max = fin.back();
+        printf("isolated launch %.1f us by events | wave entry: median %.1f max %.1f us | prologue (query load + first tile): median %.1f max %.1f us | "
+               "tile loop ends: min %.1f median %.1f max %.1f us\n", ms1 * 1e3, e_med, e_max, p_med, p_max, f_min, f_med, f_max);
+    }
 #endif
     return 0;
 }

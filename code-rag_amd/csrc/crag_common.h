@@ -129,8 +129,12 @@ struct MfmaArgs {
     uint32_t* progress;
     int ahead_max;
 };
-#define CRAG_AHEAD_MAX_DEFAULT 8
-#define CRAG_PACE_EVERY_DEFAULT 8
+// defaults (env CRAG_AHEAD_MAX / CRAG_PACE_EVERY override them for A/B runs).  Batch-1024 top-100, last level, one box
+// (profiles/r03_pacing_traffic.txt): ahead 8 reads 12.3 GB per launch (1.22 x the algorithmic 10.1 GB) whatever the
+// check interval, ahead <= 6 reads 10.3 GB (1.02 x) -- the drift the XCD's 4-MiB L2 tolerates ends between 6 and 8 tiles;
+// checking every 4th tile with ahead 4 costs no time against 8 / 8, checking every 8th with ahead 4 costs 3.5 %.
+#define CRAG_AHEAD_MAX_DEFAULT 4
+#define CRAG_PACE_EVERY_DEFAULT 4
 #define CRAG_PROGRESS_WORDS(n_cus) ((long long)((n_cus) / 8 * 8) * 32)
 // query-stationary MFMA scans; their samples are query-minor ([row][stride], or tile-major for crag_scan_q16.hip)
 // same contract for 1024-element rows (two K-parts per tile, four LDS buffers): crag_scan_qsplit.hip

@@ -346,6 +346,7 @@ def main():
                                        "/root/reference, this image or the GPU box, and there is no network (BASELINE.md 3.4)"}]
         line["regimes"] += extra_regimes(col, q, n, d, torch)
         line["cpu_baseline"] = cpu_baseline(rows, q, n, d, top_k, args.cpu_sample_rows, torch, np)
+        line["cpu_baseline"]["hnsw"] = hnsw_leg(ch, rows, q, n, d, top_k, local_rank, torch, np)
         col.close()
         del col, rows, name_hash, path_class
         torch.cuda.empty_cache()
@@ -710,7 +711,8 @@ def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
     fast = blas if blas["value"] >= port["value"] else port
     import importlib.util
     chroma = ("unavailable: chromadb not installed on this box (BASELINE.md 3.3), so the reference's Chroma+HybridSearcher "
-              "CPU path and recall@k against its HNSW result cannot be measured; the exact search has recall 1 by construction")
+              "CPU path and recall@k against its HNSW result cannot be measured; the exact search has recall 1 by construction. "
+              "cpu_baseline.hnsw holds the same measurement against a restatement of that index (oracle/hnsw_oracle.c, parity unpinned)")
     if importlib.util.find_spec("chromadb"):
         # the reference's own call sequence on a bounded slice (tools/chroma_baseline.py); never fatal to the bench
         try:
@@ -728,6 +730,82 @@ def cpu_baseline(rows, q, n, d, top_k, sample_rows, torch, np):
             "host_cpus_visible": os.cpu_count(), "port": port, "blas": blas,
             "sample": f"{nq} queries x first {m} of {n} rows: C port {dt:.2f} s on {cores} OpenMP threads, numpy/BLAS "
                       f"{dt_blas:.2f} s on {blas_threads} BLAS threads; value = the faster leg's sample q/s x {m}/{n}"}
+
+
+def hnsw_leg(ch, rows, q, n, d, top_k, device, torch, np, sample_rows=100_000, nq=256):
+    """The approximate-index CPU leg: what hybrid_search.py:60-64 runs is Chroma's HNSW index, not a brute-force scan.
+    oracle/hnsw_oracle.c restates hnswlib's published algorithm with Chroma's documented defaults (l2, M = 16,
+    ef_construction = 100, ef_search = 100; PARITY UNPINNED: chromadb / chroma-hnswlib are not installable here).  On the
+    first `sample_rows` rows: build (all host threads), `nq` queries -> 2*top_k candidates -> the oracle's rerank (R1-R5),
+    timed; recall of its candidates against the exact 2*top_k, and of its final top_k against the GPU path's answer on
+    the same rows (the north_star's "recall@k against the reference's HNSW result").  An HNSW query costs ~log(rows), so
+    its q/s on the sample is an UPPER bound for the full corpus.  Isotropic synthetic rows are the hardest case for a
+    graph index (real embeddings cluster), so the same measurement is repeated on a clustered synthetic corpus of the
+    same shape (1000 centres, rows = centre + 0.5 x unit noise, renormalised, bf16)."""
+    from oracle import coracle, hnsw
+    m = min(sample_rows, n)
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    kc = 2 * top_k
+    ef = hnsw.CHROMA_DEFAULTS["ef_search"]
+
+    def one(rows_dev, q_dev):
+        X = rows_dev.float().cpu().numpy()
+        Q = q_dev.float().cpu().numpy()
+        t0 = time.perf_counter()
+        ix = hnsw.HnswIndex(X, threads=cores, M=hnsw.CHROMA_DEFAULTS["M"], ef_construction=hnsw.CHROMA_DEFAULTS["ef_construction"])
+        t_build = time.perf_counter() - t0
+        ix.query(Q[:8], kc, threads=cores)  # warm
+        zeros_c = np.zeros(len(X), np.uint8)
+        t0 = time.perf_counter()
+        ids, dist = ix.query(Q, kc, ef_search=ef, threads=cores)
+        final = []
+        for b in range(len(Q)):
+            ok = ids[b] >= 0
+            order, _ = coracle.rerank(dist[b][ok], zeros_c[ids[b][ok]], np.zeros(int(ok.sum()), np.uint8), top_k, 2.0)
+            final.append(ids[b][ok][order])
+        t_query = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ix.query(Q[:64], kc, ef_search=ef, threads=1)
+        t_one = time.perf_counter() - t0
+        stats = ix.stats()
+        ix.close()
+        # exact candidates of the same rows (float32 BLAS) and the GPU path's final answer on them
+        d2 = (X * X).sum(1)[None, :] - 2.0 * (Q @ X.T)
+        exact = np.argsort(d2, axis=1, kind="stable")[:, :kc]
+        rec_c = float(np.mean([len(set(ids[b].tolist()) & set(exact[b].tolist())) / kc for b in range(len(Q))]))
+        sub = ch.GpuCollection(d, "bf16", "l2", device=device)
+        sub.attach_device(rows_dev, None, None)
+        sub.finalize()
+        g_ids, _, _, g_cn = sub.search_device(q_dev.contiguous(), top_k, 2.0)
+        torch.cuda.synchronize()
+        g_ids, g_cn = g_ids.cpu().numpy(), g_cn.cpu().numpy()
+        sub.close()
+        rec_f = float(np.mean([len(set(final[b].tolist()) & set(g_ids[b, :g_cn[b]].tolist())) / max(int(g_cn[b]), 1)
+                               for b in range(len(Q))]))
+        return {"rows": len(X), "build_seconds": round(t_build, 2), "queries_per_s": round(len(Q) / t_query, 1),
+                "queries_per_s_one_thread": round(64 / t_one, 1),
+                "recall_of_its_%d_candidates_vs_exact" % kc: round(rec_c, 4),
+                "recall_at_%d_of_its_answer_vs_the_gpu_path" % top_k: round(rec_f, 4),
+                "mean_degree_level0": round(stats["mean_degree_level0"], 2), "max_level": stats["max_level"]}
+
+    out = {"what": "HNSW restatement (oracle/hnsw_oracle.c: hnswlib's published algorithm, Chroma defaults l2 / M=16 / "
+                   "ef_construction=100 / ef_search=100; parity unpinned) + the oracle's rerank, on the first %d of %d rows; "
+                   "%d threads for the build and for the queries" % (m, n, cores), "threads": cores}
+    out.update(one(rows[:m], q[:nq]))
+    dev = rows.device
+    g = torch.Generator(device=dev).manual_seed(4321)
+    centres = torch.randn((1000, d), generator=g, device=dev)
+    centres /= centres.norm(dim=1, keepdim=True)
+
+    def draw(k):
+        noise = torch.randn((k, d), generator=g, device=dev)
+        x = centres[torch.randint(0, 1000, (k,), generator=g, device=dev)] + 0.5 * noise / noise.norm(dim=1, keepdim=True)
+        return (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+
+    out["clustered_corpus_same_shape"] = one(draw(m), draw(nq))
+    out["note"] = ("q/s on the sample is an upper bound for the full corpus (cost ~ log rows); isotropic rows (the bench corpus) are the "
+                   "hardest case for a graph index: its recall there is a lower bound for real embeddings, which cluster")
+    return out
 
 
 if __name__ == "__main__":

@@ -35,8 +35,8 @@ _REG = re.compile(r"\b([av])(?:(\d+)\b|\[(\d+):(\d+)\])")
 
 
 def check_fixed_register_isa(asm_path, kernel_re, n_kernels, hidden_vgpr_from, live_vgprs=None):
-    """crag_scan_qreg2.hip and crag_scan_qsplit.hip keep their query fragments in fixed registers the compiler
-    is not told about (gen_qreg2_kloop.py / gen_qsplit_kloop.py: all AGPRs, and for qreg2 at KS = 48 also
+    """crag_scan_q16.hip and crag_scan_qsplit.hip keep their query fragments in fixed registers the compiler
+    is not told about (gen_q16_kloop.py / gen_qsplit_kloop.py: all AGPRs, and for q16 at KS = 48 also
     v[128:255]).  The generated statements list them as clobbers, so nothing of the compiler's lives there
     ACROSS a statement; this check proves on the emitted ISA that no compiler-generated instruction touches
     them BETWEEN statements either.  hidden_vgpr_from(match) -> first hidden VGPR of that kernel, or None.

@@ -523,14 +523,14 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     //              VALU-bound (6-8 queries 0.90-1.0 / 0.75)
     const int path = h0->force_path;  // 0 auto, 1 GEMV, 2 MFMA, 3 tiled MFMA (tests, bench, tools)
     const bool bf16 = h0->dtype == CRAG_BF16;
-    const bool can_qreg = bf16 && crag_q16_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
+    const bool can_q16 = bf16 && crag_q16_supported(h0->dim_pad), can_qsplit = bf16 && crag_qsplit_supported(h0->dim_pad);
     const bool can_qlong = crag_qlong_supported(h0->dtype, h0->dim_pad);
     int mfma_from;
     if (can_qsplit) mfma_from = 1;
-    else if (can_qreg) mfma_from = h0->dim_pad >= 768 ? (h0->n_rows >= 4000000 ? 1 : 2) : (h0->dim_pad >= 512 || P.M > 64 ? 3 : 5);
+    else if (can_q16) mfma_from = h0->dim_pad >= 768 ? (h0->n_rows >= 4000000 ? 1 : 2) : (h0->dim_pad >= 512 || P.M > 64 ? 3 : 5);
     else if (bf16) mfma_from = CRAG_QLONG_FROM;
     else mfma_from = h0->dim_pad <= 192 ? 5 : CRAG_QLONG_FROM_F32;
-    P.mfma = same_handle && (can_qreg || can_qsplit || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
+    P.mfma = same_handle && (can_q16 || can_qsplit || can_qlong) && (path >= 2 || (path == 0 && B >= mfma_from));
 
     const bool qsplit = P.mfma && can_qsplit;  // 1024-element rows: flat buffers, row-major sample
     // (the LDS-tiled scan, crag_scan_qlong.hip: flat buffers and a row-major sample as well)
@@ -539,7 +539,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     // MFMA scan runs the multi-level cascade in which a level continues where the previous one
     // stopped.  (A one-block scan for bf16 rows up to 768 elements served two queries at top-10 until round 2;
     // the two-block cascade was within 1 % of it there, same box, and it went.)
-    const bool segmented = P.mfma && can_qreg;
+    const bool segmented = P.mfma && can_q16;
     const bool cascade = P.mfma;
     // ---- descriptors ----
     SmallVec<QueryDesc, 64> qd;
@@ -607,7 +607,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
     if ((rc = ws->desc.ensure(desc_bytes))) return rc;
     if ((rc = ws->tau.ensure(sizeof(float) * (size_t)B))) return rc;
     if ((rc = ws->cntst.ensure(sizeof(uint32_t) * ((size_t)B * CRAG_CNT_STRIDE + (size_t)B)))) return rc;
-    const bool qreg = P.mfma;  // every MFMA scan writes a query-minor sample: [row][bpad] or tile-major
+    const bool query_minor = P.mfma;  // every MFMA scan writes a query-minor sample: [row][bpad] or tile-major
     const long long bpad = ((long long)B + 15) / 16 * 16;
     if ((rc = ws->sample.ensure(sizeof(uint32_t) * (size_t)std::max<long long>(B, bpad) * (size_t)P.sample_stride))) return rc;
     const bool merged = !noalloc && ws->merged_bytes != 0;
@@ -676,7 +676,7 @@ int search_entries_chunk_launch(crag_index* const* hs, bool same_handle, const v
         ma.metric = h0->metric;
         ma.tau = tau;
         ma.sample = sample;
-        ma.sample_stride = qreg ? bpad : P.sample_stride;  // qreg: row-major sample [row][bpad]
+        ma.sample_stride = query_minor ? bpad : P.sample_stride;
         ma.cand = cand;
         ma.cnt = cnt;
         ma.segcnt = segcnt;
@@ -1610,13 +1610,13 @@ int crag_debug_dense_scores(crag_index* h, const void* queries_dev, int B, int p
         a.sample = (uint32_t*)ws->sample.p;
         a.sample_stride = stride;
         const bool d_qsplit = d_bf16 && crag_qsplit_supported(h->dim_pad);
-        const bool d_qreg2 = d_bf16 && crag_q16_supported(h->dim_pad);
+        const bool d_q16 = d_bf16 && crag_q16_supported(h->dim_pad);
         const bool d_qlong = crag_qlong_supported(h->dtype, h->dim_pad);
-        if (!d_qsplit && !d_qreg2 && !d_qlong) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
+        if (!d_qsplit && !d_q16 && !d_qlong) return fail(CRAG_E_INVALID, "mfma path: rows of this length have no MFMA scan");
         rowmajor = true;
         bpad = ((long long)B + 15) / 16 * 16;
-        tiled = d_qreg2;  // crag_launch_scan_q16's tile-major sample
-        if (d_qreg2 || d_qsplit) {
+        tiled = d_q16;  // crag_launch_scan_q16's tile-major sample
+        if (d_q16 || d_qsplit) {
             if ((rc = ws->qscan.ensure((size_t)B * h->dim_pad * 2))) return rc;
             if (crag_q16_scale_queries(q, B, h->dim_pad, h->metric, ws->qscan.p, st)) return fail(CRAG_E_HIP, "query scaling launch failed");
             a.queries = ws->qscan.p;

@@ -53,7 +53,7 @@ struct Q16Dma {
 #ifdef Q16_PROFILE  // diagnostic build only (tools/q16_bench.hip): shader-cycle stamps; the shipped kernel executes none
 #define Q16_PROF_NOW() __builtin_readcyclecounter()
 #endif
-#ifndef Q16_KLOOP_INC  // tools/qreg_bench.hip substitutes ablation builds of the statements
+#ifndef Q16_KLOOP_INC  // tools/q16_bench.hip substitutes ablation builds of the statements
 #define Q16_KLOOP_INC "crag_q16_kloop.inc"
 #endif
 #include Q16_KLOOP_INC

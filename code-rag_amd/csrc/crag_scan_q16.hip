@@ -224,6 +224,7 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     const unsigned x_lane = lds_base + (l2 ? XN_BASE + wave * Q16_XN_BYTES : ZERO_BASE) + 16 * fg;
     const unsigned x_step = l2 ? Q16_WAVES * Q16_XN_BYTES : 0;
     if (tid < 64) ((unsigned*)(lds + ZERO_BASE))[tid] = 0u;  // visible to every wave behind the prologue's barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... because the store has left this wave before it reaches that barrier
 
     // prologue: two tiles in flight, wait for the first (issuing them ahead of the query load was tried: the
     // prologue stays ~15 us either way and the whole kernel came out 0.7 % slower)

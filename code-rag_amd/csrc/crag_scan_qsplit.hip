@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
     const unsigned x_lane = lds_base + (l2 ? QS_XN_BASE + wave * QS_XN_BYTES : QS_ZERO_BASE) + 16 * fg;
     const unsigned x_step = l2 ? QS_WAVES * QS_XN_BYTES : 0;
     if (tid < 64) ((unsigned*)(lds + QS_ZERO_BASE))[tid] = 0u;  // visible to every wave behind the prologue's barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... because the store has left this wave before it reaches that barrier
 
     // half-tile h of this workgroup's sequence lives in buffer h % 4; tile i = half-tiles 2 i (part 0) and 2 i + 1.
     // prologue: half-tiles 0, 1, 2 in flight, wait for the first

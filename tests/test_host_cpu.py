@@ -363,3 +363,15 @@ def test_isa_guards_catch_the_gemv_faults_of_round_2(tmp_path):
         f.write_text(t)
         with pytest.raises(RuntimeError):
             b.check_gemv_isa(str(f))
+
+
+@pytest.mark.parametrize("gen,inc", [("gen_q16_kloop.py", "crag_q16_kloop.inc"), ("gen_qsplit_kloop.py", "crag_qsplit_kloop.inc")])
+def test_generated_tile_statements_are_what_their_generators_emit(gen, inc):
+    """The inline-asm tile statements the scan kernels include are generated files: the committed text must be the
+    generator's output with its default settings (an ablation build left behind would ship a different kernel)."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "code-rag_amd", "csrc")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("Q16_")}
+    out = subprocess.run([sys.executable, os.path.join(csrc, gen)], capture_output=True, text=True, check=True, env=env).stdout
+    assert out == open(os.path.join(csrc, inc)).read()

@@ -1395,6 +1395,11 @@ int crag_index_finalize(crag_index* h) {
         if (rc) return fail(CRAG_E_HIP, "row_norms launch failed");
     }
     HIPCHK(hipMemcpy(&h->max_xnorm, mx, 4, hipMemcpyDeviceToHost));
+    if (!(h->max_xnorm <= 3.4028234663852886e38f)) {
+        // the error bound of the certificates is built on max |x|^2: a collection with such a row cannot be searched exactly
+        h->max_xnorm = 0.f;
+        return fail(CRAG_E_INVALID, "a row holds a NaN or an infinite value (or its squared norm overflows float32)");
+    }
     // certificates of crag_search_device_noalloc: that entry point may not allocate, so its pinned block is made here
     if (!h->na_status) HIPCHK(hipHostMalloc((void**)&h->na_status, sizeof(uint32_t) * CRAG_NOALLOC_MAX_B, hipHostMallocDefault));
     h->finalized = true;

@@ -167,7 +167,10 @@ __global__ __launch_bounds__(64 * Q16_WAVES, 1) void k_scan_q16(const unsigned s
     const int seg = (stream * 8 + xcd) * 4 + fg;  // < n_seg
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-        tq[jb] = -__builtin_inff();
+        // a lane without a query holds a COPY of the batch's last query (the clamped load above): its threshold is a NaN,
+        // which no score is at or below -- -inf would let the scores of a query with an infinite component through,
+        // and the append would land behind the last query's buffer
+        tq[jb] = __builtin_nanf("");
         pos[jb] = 0;
         if (MODE == 1 && ok[jb]) {
             tq[jb] = tau[qn[jb]];

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_scan_qlong(const unsigned char* __re
     for (int j = 0; j < FJ; ++j) {
         const int q = q0 + (wc * FJ + j) * 32 + fr;
         const bool qok = q < n_queries;
-        const float tq = (MODE == 1 && qok) ? tau[q] : -__builtin_inff();
+        // a lane past the batch multiplied a copy of the last query: NaN, not -inf, so that not even a -inf score passes
+        const float tq = (MODE == 1 && qok) ? tau[q] : __builtin_nanf("");
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
             const long long mb = row0 + (wr * FI + i) * 32 + 4 * fh;

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(64 * QS_WAVES, 1) void k_scan_qsplit(const unsigned
     // stationary B operands: this lane's two queries, k = 32 s + 8 fg + [0,8), in fixed AGPRs
     qsplit_load(queries + (long long)(ok0 ? q0 : n_queries - 1) * QS_D + 8 * fg,
                 queries + (long long)(ok1 ? q1 : n_queries - 1) * QS_D + 8 * fg);
-    float tq0 = -__builtin_inff(), tq1 = -__builtin_inff();
+    // a lane without a query holds a copy of the batch's last query: its threshold is a NaN, which no score is at or below
+    // (-inf would let the -inf scores of a query with an infinite component through, towards a buffer that does not exist)
+    float tq0 = __builtin_nanf(""), tq1 = __builtin_nanf("");
     if (MODE == 1 && ok0) tq0 = tau[q0];
     if (MODE == 1 && ok1) tq1 = tau[q1];
 

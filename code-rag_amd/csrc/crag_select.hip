@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void k_row_norms(const uint4* __restrict__ row
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         const float f = (float)acc;
         if (lane == 0) xnorm[r] = f;
-        wmax = fmaxf(wmax, f);
+        // a NaN would slip through fmaxf: a row that is not a vector of finite numbers reads as an infinite norm
+        wmax = fmaxf(wmax, f == f ? f : __builtin_inff());
     }
     if (lane == 0) atomicMax(max_bits, __builtin_bit_cast(unsigned int, wmax));
 }
@@ -450,6 +451,20 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs a) {
         __syncthreads();
     }
     const double qn = red[0];
+    if (!(qn <= 1.7976931348623157e308)) {
+        // a query with a NaN or an infinite component (or a norm beyond float64) has no nearest neighbours: no results,
+        // nothing for the fallback tiers to settle.  (The reference cannot get here: its queries come out of the embedder.)
+        CragEntry* o = a.entries + (long long)q * a.kc;
+        for (int i = tid; i < a.kc; i += blockDim.x) {
+            CragEntry e;
+            e.dist = __builtin_inff();
+            e.flags = 0;
+            e.id = 0x7fffffffffffffffll;
+            o[i] = e;
+        }
+        if (tid == 0) a.status[q] = CRAG_ST_OK;
+        return;
+    }
 
     // exact re-scoring: 8 lanes per candidate.  The query and the candidates' rows are first staged in LDS with
     // coalesced 16-byte loads, all in flight at once (the sorted keys occupy skeys[0 .. m]; the rest of that

@@ -100,7 +100,9 @@ int crag_index_set_symbols(crag_index* h, const uint64_t* hashes, const uint16_t
  * what persistence writes to disk, so that no second copy of the embeddings has to live in host memory.
  */
 int crag_index_get_rows(const crag_index* h, int64_t first, int64_t n, void* out_rows);
-/* Row norms + bounds; required after the last add and before the first search. */
+/* Row norms + bounds; required after the last add and before the first search.  CRAG_E_INVALID when a row holds a NaN
+ * or an infinite value (the exactness certificates are built on max |x|^2; Chroma's behaviour on such rows is not
+ * defined either).  A QUERY with a non-finite component is not an error: it gets no results (count 0). */
 int crag_index_finalize(crag_index* h);
 
 /* ---- symbol hashing (R3) -------------------------------------------------------------- */

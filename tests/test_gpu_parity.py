@@ -1278,3 +1278,42 @@ def test_concurrent_searches_from_several_threads_are_exact(coracle):
         t.join()
     assert not errors, errors[:3]
     assert sum(c.stats()["fallback"] for c in cols) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,d,nq,path", [("bf16", 768, 40, "mfma"), ("f32", 384, 3, "gemv"), ("bf16", 1024, 9, "mfma"), ("f32", 384, 40, "mfma"),
+                                              ("bf16", 768, 300, "mfma")])
+def test_non_finite_queries_get_no_results_and_leave_the_others_exact(coracle, dtype, d, nq, path):
+    """A query with a NaN or an infinite component has no nearest neighbours: count 0, and the other queries of the
+    batch are answered exactly as without it (no fallback storm, no fault).  Not reference behaviour: undefined there."""
+    rows, queries, classes, _ = synth_case(20000, d, dtype, nq, seed=61)
+    col = make_collection(rows, dtype, "l2", classes=classes)
+    col.set_path(path)
+    bad = queries.copy()
+    bad[0, 5] = np.uint16(0x7fc0) if dtype == "bf16" else np.float32("nan")
+    bad[nq - 1, d - 1] = np.uint16(0xff80) if dtype == "bf16" else np.float32("-inf")
+    ids, sc, di, cn = col.search(to_f32(bad), 10, 2.0, query_texts=[""] * nq)
+    assert cn[0] == 0 and cn[nq - 1] == 0
+    want = coracle.search_numeric(rows, queries, classes, None, 10, 2.0, "l2")
+    for b in range(1, nq - 1):
+        wi, ws, wd = want[b]
+        n = len(wi)
+        assert int(cn[b]) == n
+        assert np.array_equal(ids[b, :n], wi) and np.array_equal(sc[b, :n], ws)
+        assert np.array_equal(di[b, :n].view(np.uint32), wd.view(np.uint32))
+    assert col.stats()["exact_scan"] == 0
+    col.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,d", [("bf16", 768), ("f32", 384)])
+@pytest.mark.parametrize("what", ["nan", "-nan", "inf"])
+def test_a_collection_with_a_non_finite_row_is_rejected_at_finalize(dtype, d, what):
+    rows, _, classes, _ = synth_case(3000, d, dtype, 1, seed=62)
+    rows = rows.copy()
+    if dtype == "bf16":
+        rows[1234, 7] = {"nan": 0x7fc0, "-nan": 0xffc0, "inf": 0x7f80}[what]
+    else:
+        rows.view(np.uint32)[1234, 7] = {"nan": 0x7fc00000, "-nan": 0xffc00000, "inf": 0x7f800000}[what]
+    with pytest.raises(ch.CragError, match="NaN or an infinite"):
+        make_collection(rows, dtype, "l2", classes=classes)

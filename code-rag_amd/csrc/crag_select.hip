@@ -615,8 +615,11 @@ __global__ __launch_bounds__(256) void k_merge_rerank(const CragEntry* __restric
     for (int i = tid; i < n; i += blockDim.x) {
         const int g = i / kc, j = i - g * kc;
         const CragEntry e = entries[((long long)g * B + q) * kc + j];
-        ids[i] = e.id;
-        fk[i] = crag_fkey(e.dist);
+        // an entry with a NaN distance (only a caller of crag_merge_rerank_device can hand one in) counts as padding: with
+        // its own key it could rank ahead of real entries or behind padding and leave a hole in sel[]
+        const bool nan = e.dist != e.dist;
+        ids[i] = nan ? 0x7fffffffffffffffll : e.id;
+        fk[i] = nan ? 0xffffffffu : crag_fkey(e.dist);
         fl[i] = e.flags;
     }
     __syncthreads();

@@ -1317,3 +1317,29 @@ def test_a_collection_with_a_non_finite_row_is_rejected_at_finalize(dtype, d, wh
         rows.view(np.uint32)[1234, 7] = {"nan": 0x7fc00000, "-nan": 0xffc00000, "inf": 0x7f800000}[what]
     with pytest.raises(ch.CragError, match="NaN or an infinite"):
         make_collection(rows, dtype, "l2", classes=classes)
+
+
+@pytest.mark.gpu
+def test_merge_treats_nan_distance_entries_as_padding():
+    """crag_merge_rerank_device takes entries from its caller (the all-gather of the shards): an entry whose distance
+    is a NaN -- either sign -- must read as padding, not rank among the real ones or leave a gap in the ranking."""
+    import torch
+    from coderag_hip.collection import merge_rerank_device
+    entry = np.dtype([("dist", "<f4"), ("flags", "<u4"), ("id", "<i8")])
+    G, B, top_k = 3, 2, 4
+    kc = 2 * top_k
+    e = np.zeros((G, B, kc), entry)
+    e["dist"], e["id"] = np.inf, 0x7fffffffffffffff           # all padding
+    real = [(0.25, 7), (0.5, 3), (1.0, 11), (1.0, 5), (3.0, 2)]
+    for n, (d, i) in enumerate(real):
+        e[n % G, 0, n // G] = (d, 0, i)
+    e[0, 0, 5] = (np.float32("nan"), 0, 100)                  # NaN entries between real ones and padding
+    e[1, 0, 4]["dist"], e[1, 0, 4]["id"] = -np.float32("nan"), 101
+    e[2, 1, 0] = (np.float32("nan"), 0, 102)                  # a query with nothing but a NaN entry
+    t = torch.from_numpy(e.view(np.uint8).reshape(G, B, kc, 16).copy()).cuda()
+    ids, sc, di, cn = merge_rerank_device(0, t, G, B, top_k, 2.0)
+    torch.cuda.synchronize()
+    ids, sc, di, cn = ids.cpu().numpy(), sc.cpu().numpy(), di.cpu().numpy(), cn.cpu().numpy()
+    assert cn.tolist() == [4, 0]
+    assert ids[0].tolist() == [7, 3, 5, 11]                   # (distance, id) order; base score 1 / (1 + d)
+    assert np.allclose(sc[0], [0.8, 1 / 1.5, 0.5, 0.5]) and (ids[1] == -1).all()

@@ -1343,3 +1343,31 @@ def test_merge_treats_nan_distance_entries_as_padding():
     assert cn.tolist() == [4, 0]
     assert ids[0].tolist() == [7, 3, 5, 11]                   # (distance, id) order; base score 1 / (1 + d)
     assert np.allclose(sc[0], [0.8, 1 / 1.5, 0.5, 0.5]) and (ids[1] == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,d,nq,path", [("bf16", 768, 40, "mfma"), ("f32", 384, 3, "gemv"), ("bf16", 1024, 9, "mfma"), ("f32", 384, 40, "mfma")])
+def test_queries_whose_scores_overflow_float32_go_through_every_tier_without_harm(coracle, dtype, d, nq, path):
+    """A query with a component near the float32 maximum is finite (its |q|^2 fits float64), but every scan score is
+    +-inf or NaN and every float32 distance is +inf: it walks through the certificate, the wide re-score, the certified
+    re-scan (threshold +inf: every row is collected) and the exact scan, and ends with no result (1 / (1 + inf) = 0 is
+    not > 0.01).  The other queries of the batch stay exact."""
+    rows, queries, classes, _ = synth_case(20000, d, dtype, nq, seed=63)
+    col = make_collection(rows, dtype, "l2", classes=classes)
+    col.set_path(path)
+    bad = queries.copy()
+    huge = np.uint16(0x7f7f) if dtype == "bf16" else np.float32(3.0e38)
+    for b in (1, nq - 1):
+        bad[b, 3] = huge
+    ids, sc, di, cn = col.search(to_f32(bad), 10, 2.0, query_texts=[""] * nq)
+    assert cn[1] == 0 and cn[nq - 1] == 0
+    want = coracle.search_numeric(rows, queries, classes, None, 10, 2.0, "l2")
+    for b in range(nq):
+        if b in (1, nq - 1):
+            continue
+        wi, ws, wd = want[b]
+        n = len(wi)
+        assert int(cn[b]) == n
+        assert np.array_equal(ids[b, :n], wi) and np.array_equal(sc[b, :n], ws)
+        assert np.array_equal(di[b, :n].view(np.uint32), wd.view(np.uint32))
+    col.close()

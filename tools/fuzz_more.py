@@ -2,7 +2,8 @@
 random shapes through the auto dispatch with injected duplicates / near-duplicates (so that every fallback tier is
 hit), single-collection batches and multi-collection batches; symbol names and query texts (R3), path classes (R2),
 symbol_boost values on both sides of the 0.01 threshold (R4); the host-buffer entry point, and with FUZZ_DEVICE=1 the
-device-buffer and the no-alloc entry points compared with it.
+device-buffer and the no-alloc entry points compared with it; with FUZZ_POISON=1 batches that hold non-finite or
+overflowing queries (those get no results, the others must not notice).
 
     python tools/fuzz_more.py [cases] [seed]
 """
@@ -62,6 +63,7 @@ def names_for_match(match):
 
 
 DEVICE = os.environ.get("FUZZ_DEVICE") == "1"
+POISON = os.environ.get("FUZZ_POISON") == "1"  # also run batches with non-finite / overflowing queries in them
 
 
 def check_device_entry_points(col, queries_bits, dtype, top_k, sb, texts, got, tag):
@@ -169,6 +171,25 @@ for case in range(n_cases):
         st = col.stats()
         for k in ("fallback", "rescan", "exact_scan"):
             tot[k] += st[k]
+        if POISON and r2.random() < 0.5:
+            # the same batch with one or two queries replaced by vectors that are not finite (NaN, +-inf: no results) or
+            # whose scores overflow float32 (a component near the float32 maximum: every tier runs, anything may come
+            # back for THAT query); the other queries must come back exactly as before
+            bad = qf.copy()
+            where = sorted({int(nq - 1 if r2.random() < 0.5 else r2.integers(0, nq)), int(r2.integers(0, nq))})
+            kinds = []
+            for b in where:
+                kind = str(r2.choice(["nan", "inf", "-inf", "huge"]))
+                kinds.append(kind)
+                bad[b, int(r2.integers(0, d))] = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf, "huge": 3.0e38}[kind]
+            got2 = col.search(bad, top_k, sb, query_texts=texts)
+            for b, kind in zip(where, kinds):
+                if kind != "huge" and int(got2[3][b]) != 0:
+                    print("MISMATCH poisoned query", b, kind, "count", int(got2[3][b]), (case, dtype, d, n, nq, top_k, metric), flush=True)
+                    sys.exit(1)
+            keep = [b for b in range(nq) if b not in where]
+            check(tuple(g[keep] for g in got2), [want[b] for b in keep], ("poisoned", case, dtype, d, n, nq, top_k, metric, where, kinds))
+            tot["poisoned"] = tot.get("poisoned", 0) + 1
         col.close()
     else:
         ncol = int(rng.integers(2, 7))

@@ -223,6 +223,21 @@ for case in range(n_cases):
             rows, classes = data[i]
             want += coracle.search_numeric(rows, queries[b:b + 1], classes, None, top_k, 2.0, metric, 1_000_000 * i)
         check(got, want, (case, "multi", dtype, d, order, top_k, metric))
+        if POISON and rng.random() < 0.5:
+            r3 = np.random.default_rng(seed + 5)
+            bad = qf.copy()
+            where = sorted({int(len(order) - 1 if r3.random() < 0.5 else r3.integers(0, len(order))), int(r3.integers(0, len(order)))})
+            kinds = [str(r3.choice(["nan", "inf", "-inf", "huge"])) for _ in where]
+            for b, kind in zip(where, kinds):
+                bad[b, int(r3.integers(0, d))] = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf, "huge": 3.0e38}[kind]
+            got2 = ch.search_multi([cols[i] for i in order], bad, top_k, 2.0)
+            for b, kind in zip(where, kinds):
+                if kind != "huge" and int(got2[3][b]) != 0:
+                    print("MISMATCH poisoned query", b, kind, "count", int(got2[3][b]), (case, "multi", dtype, d, order, top_k, metric), flush=True)
+                    sys.exit(1)
+            keep = [b for b in range(len(order)) if b not in where]
+            check(tuple(g[keep] for g in got2), [want[b] for b in keep], ("poisoned", case, "multi", dtype, d, order, top_k, metric, where, kinds))
+            tot["poisoned"] = tot.get("poisoned", 0) + 1
         st = cols[order[0]].stats()
         for k in ("fallback", "rescan", "exact_scan"):
             tot[k] += st[k]
